@@ -1,0 +1,242 @@
+"""ctypes binding of libbwahip.so -- the host-side mirror of the reference interface.
+
+The product is the C-ABI shared library (include/bwahip.h); this module only makes it callable from
+the Python test-suite and bench.py.  It never computes anything itself and it never falls back to a
+CPU implementation: if the HIP library has not been built, importing the library fails loudly.
+
+Mirrors: mem_opt_t / mem_opt_init (bwa.h:86, bwamem.c:74), mem_process_seqs (bwamem.h:69),
+mem_align1_core (bwamem.c:1061) and the stage boundaries used by the parity tests.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("BWAHIP_LIB") or os.path.join(_HERE, "libbwahip.so")
+TOOLS = os.path.join(_HERE, "tools")
+
+
+class Opt(C.Structure):  # bwahip_opt_t == mem_opt_t (bwa.h:86-118)
+    _fields_ = [("max_mem_intv", C.c_uint64), ("a", C.c_int), ("b", C.c_int), ("o_del", C.c_int), ("e_del", C.c_int),
+                ("o_ins", C.c_int), ("e_ins", C.c_int), ("pen_unpaired", C.c_int), ("pen_clip5", C.c_int),
+                ("pen_clip3", C.c_int), ("w", C.c_int), ("zdrop", C.c_int), ("T", C.c_int), ("flag", C.c_int),
+                ("min_seed_len", C.c_int), ("min_chain_weight", C.c_int), ("max_chain_extend", C.c_int),
+                ("split_factor", C.c_float), ("split_width", C.c_int), ("max_occ", C.c_int), ("max_chain_gap", C.c_int),
+                ("n_threads", C.c_int), ("chunk_size", C.c_int), ("mask_level", C.c_float), ("drop_ratio", C.c_float),
+                ("XA_drop_ratio", C.c_float), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float),
+                ("mapQ_coef_fac", C.c_int), ("max_ins", C.c_int), ("max_matesw", C.c_int), ("max_XA_hits", C.c_int),
+                ("max_XA_hits_alt", C.c_int), ("mat", C.c_int8 * 25)]
+
+
+class Seq(C.Structure):  # bwahip_seq_t == bseq1_t (bwa.h:58-63)
+    _fields_ = [("l_seq", C.c_int), ("id", C.c_int), ("name", C.c_char_p), ("comment", C.c_char_p),
+                ("seq", C.POINTER(C.c_char)), ("qual", C.c_char_p), ("sam", C.POINTER(C.c_char)),
+                ("l_name", C.c_int8), ("l_comment", C.c_int8), ("l_qual", C.c_int16)]
+
+
+class AlnReg(C.Structure):  # bwahip_alnreg_t == mem_alnreg_t (bwa.h:145-163)
+    _fields_ = [("rb", C.c_int64), ("re", C.c_int64), ("hash", C.c_uint64), ("frac_rep", C.c_float),
+                ("qb", C.c_int), ("qe", C.c_int), ("rid", C.c_int), ("score", C.c_int), ("truesc", C.c_int),
+                ("sub", C.c_int), ("alt_sc", C.c_int), ("csub", C.c_int), ("sub_n", C.c_int), ("w", C.c_int),
+                ("seedcov", C.c_int), ("secondary", C.c_int), ("secondary_all", C.c_int), ("seedlen0", C.c_int),
+                ("n_comp", C.c_int, 30), ("is_alt", C.c_int, 2)]
+
+
+class AlnRegV(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("a", C.POINTER(AlnReg))]
+
+
+class PeStat(C.Structure):
+    _fields_ = [("low", C.c_int), ("high", C.c_int), ("failed", C.c_int), ("avg", C.c_double), ("std", C.c_double)]
+
+
+ERRORS = {0: "ok", -1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "EIO", -5: "ECAPACITY", -6: "EINTERNAL"}
+
+STAGE_INTV, STAGE_CHAIN, STAGE_CHAIN_FLT, STAGE_REGS, STAGE_REGS_PRE, STAGE_SEEDS = 1, 2, 3, 4, 5, 6
+TAG_READ = 100
+
+
+class BwahipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libbwahip.so.  There is no fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BwahipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the hot path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i64p, u64p, ip = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)
+    L.bwahip_version.restype = C.c_char_p
+    L.bwahip_opt_init.argtypes = [C.POINTER(Opt)]
+    L.bwahip_init_from_files.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.bwahip_destroy.argtypes = [vp]
+    L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
+    L.bwahip_batch_upload.argtypes = [vp, C.c_int, vp, vp]
+    L.bwahip_batch_run.argtypes = [vp, C.POINTER(Opt), C.POINTER(C.c_float), C.c_int]
+    L.bwahip_batch_counters.argtypes = [vp, u64p, C.c_int]
+    L.bwahip_kernel_name.restype = C.c_char_p
+    L.bwahip_kat_occ4.argtypes = [vp, C.c_int, vp, vp]
+    L.bwahip_kat_sa.argtypes = [vp, C.c_int, vp, vp]
+    L.bwahip_kat_extend.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.bwahip_kat_ksw_extend.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.bwahip_align_batch.argtypes = [vp, C.POINTER(Opt), C.c_int, C.POINTER(Seq), C.POINTER(AlnRegV)]
+    L.bwahip_process_seqs.argtypes = [vp, C.POINTER(Opt), C.c_int64, C.c_int, C.POINTER(Seq), C.POINTER(PeStat)]
+    L.bwahip_batch_download.argtypes = [vp, C.POINTER(AlnRegV)]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise BwahipError(f"{what} failed: {ERRORS.get(rc, rc)}")
+
+
+def default_opt():
+    o = Opt()
+    lib().bwahip_opt_init(C.byref(o))
+    return o
+
+
+NT4 = np.full(256, 4, dtype=np.uint8)
+for _c, _v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+    NT4[_c] = _v
+NT4[ord("-")] = 5
+
+
+def pack_reads(reads):
+    """list of ASCII/bytes reads -> (codes uint8 concatenated, offsets int64[n+1])."""
+    lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    buf = b"".join(r if isinstance(r, bytes) else r.encode() for r in reads)
+    codes = NT4[np.frombuffer(buf, dtype=np.uint8)] if buf else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(codes), off
+
+
+def parse_records(words):
+    """int64 record stream [tag, n, n values]* -> list of (tag, ndarray)."""
+    out, i, n = [], 0, len(words)
+    while i < n:
+        tag, cnt = int(words[i]), int(words[i + 1])
+        out.append((tag, words[i + 2:i + 2 + cnt]))
+        i += 2 + cnt
+    return out
+
+
+def read_record_file(path):
+    return parse_records(np.fromfile(path, dtype=np.int64))
+
+
+class Context:
+    """One GPU, one index resident in HBM (bwahip_ctx)."""
+
+    def __init__(self, prefix, device=0):
+        self._h = C.c_void_p()
+        _check(lib().bwahip_init_from_files(os.fsencode(prefix), device, C.byref(self._h)), "bwahip_init_from_files")
+
+    def close(self):
+        if self._h:
+            lib().bwahip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def run_stages(self, codes, off, stages, opt=None):
+        opt = opt or default_opt()
+        mask = 0
+        for s in stages:
+            mask |= 1 << s
+        out, n = C.POINTER(C.c_int64)(), C.c_int64()
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        _check(lib().bwahip_run_stages(self._h, C.byref(opt), len(off) - 1, codes.ctypes.data, off.ctypes.data, mask,
+                                       C.byref(out), C.byref(n)), "bwahip_run_stages")
+        words = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.int64)
+        C.CDLL(None).free(out)
+        return parse_records(words)
+
+    def batch_upload(self, codes, off):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        _check(lib().bwahip_batch_upload(self._h, len(off) - 1, codes.ctypes.data, off.ctypes.data), "bwahip_batch_upload")
+
+    def batch_run(self, opt=None):
+        opt = opt or default_opt()
+        nk = lib().bwahip_n_kernels()
+        ms = (C.c_float * nk)()
+        _check(lib().bwahip_batch_run(self._h, C.byref(opt), ms, nk), "bwahip_batch_run")
+        return {lib().bwahip_kernel_name(i).decode(): float(ms[i]) for i in range(nk)}
+
+    def counters(self):
+        buf = (C.c_uint64 * 16)()
+        _check(lib().bwahip_batch_counters(self._h, buf, 16), "bwahip_batch_counters")
+        names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells"]
+        return {k: int(buf[i]) for i, k in enumerate(names)}
+
+    def kat_occ4(self, k):
+        k = np.ascontiguousarray(k, dtype=np.uint64)
+        out = np.zeros((len(k), 4), dtype=np.uint64)
+        _check(lib().bwahip_kat_occ4(self._h, len(k), k.ctypes.data, out.ctypes.data), "bwahip_kat_occ4")
+        return out
+
+    def kat_sa(self, k):
+        k = np.ascontiguousarray(k, dtype=np.uint64)
+        out = np.zeros(len(k), dtype=np.uint64)
+        _check(lib().bwahip_kat_sa(self._h, len(k), k.ctypes.data, out.ctypes.data), "bwahip_kat_sa")
+        return out
+
+    def kat_extend(self, ik3, is_back):
+        ik3 = np.ascontiguousarray(ik3, dtype=np.uint64)
+        is_back = np.ascontiguousarray(is_back, dtype=np.int32)
+        out = np.zeros((len(is_back), 12), dtype=np.uint64)
+        _check(lib().bwahip_kat_extend(self._h, len(is_back), ik3.ctypes.data, is_back.ctypes.data, out.ctypes.data), "bwahip_kat_extend")
+        return out
+
+
+# ---------------------------------------------------------------- tooling wrappers (synthetic data, index build)
+def _tool(name):
+    path = os.path.join(TOOLS, name)
+    if not os.path.exists(path):
+        raise BwahipError(f"{path} is missing: run __graft_entry__.build()")
+    return path
+
+
+def make_genome(fa, seed, lens, repeats=True):
+    subprocess.check_call([_tool("simgen"), "genome", fa, str(seed), "1" if repeats else "0"] + [str(x) for x in lens])
+
+
+def make_reads(fa, fq1, fq2, n, length, sub_ppm, indel_ppm, n_ppm, seed, chim_ppm=0):
+    subprocess.check_call([_tool("simgen"), "reads", fa, fq1, fq2 or "-", str(n), str(length), str(sub_ppm), str(indel_ppm),
+                           str(n_ppm), str(seed), str(chim_ppm)])
+
+
+def make_index(fa, prefix):
+    subprocess.check_call([_tool("mkindex"), fa, prefix])
+
+
+def read_fastq(path):
+    names, seqs, quals = [], [], []
+    with open(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            s = f.readline().rstrip(b"\r\n")
+            f.readline()
+            q = f.readline().rstrip(b"\r\n")
+            names.append(h[1:].split()[0])
+            seqs.append(s)
+            quals.append(q)
+    return names, seqs, quals

@@ -1,0 +1,104 @@
+// Internal definitions shared by the HIP translation units of libbwahip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <string>
+#include "../../include/bwahip.h"
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	fprintf(stderr, "[bwahip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(e_)); \
+	return BWAHIP_ENODEV; } } while (0)
+
+// Contig table entry in HBM (subset of bntann1_t that the kernels need; bntseq.h:41).
+struct DevAnn { int64_t offset; int32_t len; int32_t is_alt; };
+
+// Everything a kernel needs to know about the index; passed by value as a kernel argument.
+struct DevIndex {
+	const uint4 *bwt;        // Occ-interleaved BWT viewed as 64-byte blocks = 4 x uint4 (bwt.h:74-75)
+	const uint64_t *sa;      // sampled SA, sa[0] = -1 (bwt.c:83)
+	const uint8_t *pac;      // forward strand, 4 bases/byte, MSB first (bntseq.c:229)
+	const DevAnn *anns;
+	uint64_t primary, L2[5], seq_len, n_sa;
+	int64_t l_pac;
+	int sa_intv, sa_shift, n_seqs;
+};
+
+// Options the kernels read (a flat copy of the fields of mem_opt_t that the hot path uses).
+struct DevOpt {
+	int a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop;
+	int min_seed_len, split_width, max_occ, max_chain_gap, max_mem_intv, split_len;
+	int min_chain_weight, max_chain_extend;
+	float mask_level, drop_ratio, mask_level_redun;
+	int8_t mat[25];
+};
+
+// Work counters kept in HBM, bumped once per wavefront at kernel exit (bwahip_batch_counters).
+enum { CNT_EXTEND = 0, CNT_BLOCKS, CNT_SA, CNT_LF, CNT_INTV, CNT_SEEDS, CNT_CELLS, CNT_N = 16 };
+
+// One interval / list entry in HBM: x[0], x[1], x[2], info  (bwtintv_t, bwt.h:62)
+struct __attribute__((aligned(32))) DevIntv { uint64_t x0, x1, x2, info; };
+
+// Seed as produced by the SA-lookup kernel (mem_seed_t, bwa.h:121, plus the contig id of bwamem.c:293).
+struct __attribute__((aligned(16))) DevSeed { int64_t rbeg; int32_t qbeg, len; int32_t score, rid; };
+
+// Chain header as produced by the chaining kernel (mem_chain_t, bwa.h:135).
+struct DevChain {
+	int64_t pos;
+	int32_t seed_off, n;     // seeds live at chain_seeds[read_seed_base + seed_off .. +n)
+	int32_t rid, w, kept, first, is_alt;
+	float frac_rep;
+};
+
+// Alignment region in HBM (mem_alnreg_t, bwa.h:145; same field order, no bit-fields)
+struct DevReg {
+	int64_t rb, re;
+	float frac_rep;
+	int32_t qb, qe, rid, score, truesc, sub, csub, sub_n, w, seedcov, seedlen0, n_comp, is_alt;
+	int32_t pad;
+};
+
+struct HostIndex {           // host copy of a loaded index (index_io.cpp)
+	bwahip_bwt_t bwt;
+	bwahip_bns_t bns;
+	uint8_t *pac;
+	bool owned;
+};
+int bwahip_load_index_files(const char *prefix, HostIndex *out);   // index_io.cpp
+void bwahip_free_host_index(HostIndex *h);
+
+DevOpt make_dev_opt(const bwahip_opt_t *o);
+
+// ---- launch wrappers (one per kernel translation unit) ----
+struct SmemLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const uint8_t *seq; const int64_t *off;
+	DevIntv *out; int *out_n; int cap;          // per read: out[read*cap .. ), out_n[read]
+	int *seed_cnt;                              // per read: number of SA look-ups chaining will do (bwamem.c:285-286)
+	float *frac_rep_lrep;                       // unused slot (kept for layout stability)
+	int *l_rep;                                 // per read: l_rep of bwamem.c:272-279
+	DevIntv *scratch; int lcap;                 // per group: 2*lcap list entries + cap unsorted intervals
+	unsigned int *queue;                        // work-queue head
+	unsigned long long *counters;
+	int *err;
+	int groups_total;
+};
+int launch_smem(const SmemLaunch &a, int group_lanes, hipStream_t st);
+int smem_default_groups(int group_lanes);
+
+struct SeedLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const int64_t *off;
+	const DevIntv *intv; const int *intv_n; int cap;
+	const int64_t *seed_base;                   // exclusive scan of seed_cnt, n_reads+1 entries
+	DevSeed *seeds;
+	unsigned long long *counters;
+};
+int launch_seeds(const SeedLaunch &a, int64_t total_seeds, hipStream_t st);
+
+int launch_kat_occ4(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st);
+int launch_kat_sa(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st);
+int launch_kat_extend(const DevIndex &ix, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12, hipStream_t st);

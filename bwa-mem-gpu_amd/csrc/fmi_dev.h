@@ -1,0 +1,170 @@
+// Device-side FM-index primitives for gfx950.
+//
+// Work shape: one Occ block (64 B = 4 x u64 counts + 128 packed bases, bwt.h:74-75) is fetched by a
+// *quad* of 4 adjacent lanes, 16 B per lane (`global_load_dwordx4`), so every HBM request is one
+// fully used, naturally aligned 64-byte line.  Lanes 0/1 of the quad hold the four base counts,
+// lanes 2/3 hold 64 bases each and pop-count them; the partial results are combined with DPP
+// quad permutes (no LDS traffic).  The reference computes the same numbers with a 256-entry byte
+// table (bwt.c:42-51, 165-186); results are identical.
+#pragma once
+#include "bwahip_internal.h"
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// DPP helpers (all VALU, no LDS): broadcast lane K of each quad / swap the two quads of an 8-lane group.
+template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+	constexpr int ctrl = K | K << 2 | K << 4 | K << 6;      // quad_perm:[K,K,K,K]
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
+}
+template <int K> __device__ __forceinline__ uint64_t quad_bcast64(uint64_t v)
+{
+	return (uint64_t)quad_bcast<K>((uint32_t)v) | (uint64_t)quad_bcast<K>((uint32_t)(v >> 32)) << 32;
+}
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); } // [1,0,3,2]
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); } // [2,3,0,1]
+// row_half_mirror: lane i <-> 7-i inside each group of 8 lanes.  For values that are uniform inside a
+// quad this hands each quad the value of the other quad of its 8-lane group.
+__device__ __forceinline__ uint32_t half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); }
+__device__ __forceinline__ uint64_t half_mirror64(uint64_t v)
+{
+	return (uint64_t)half_mirror((uint32_t)v) | (uint64_t)half_mirror((uint32_t)(v >> 32)) << 32;
+}
+
+// Count, for each base c, the symbols equal to c among the first `n` (0..64) of the 64 bases held in
+// v (4 words, 16 bases each, first base in the top bits of v.x; bwt.h:80).  Returns 4 byte counters.
+__device__ __forceinline__ uint32_t count_bases64(uint4 v, int n)
+{
+	uint64_t hi01 = (uint64_t)v.x << 32 | v.y, hi23 = (uint64_t)v.z << 32 | v.w;   // 32 bases each, first base on top
+	int n0 = n < 32 ? n : 32, n1 = n - n0;
+	uint64_t m0 = n0 == 0 ? 0ull : ~0ull << ((32 - n0) << 1);
+	uint64_t m1 = n1 == 0 ? 0ull : ~0ull << ((32 - n1) << 1);
+	uint64_t a = hi01 & m0, b = hi23 & m1;
+	const uint64_t k5 = 0x5555555555555555ull;
+	uint64_t alo = a & k5, ahi = (a >> 1) & k5, blo = b & k5, bhi = (b >> 1) & k5;
+	uint32_t c3 = __popcll(ahi & alo) + __popcll(bhi & blo);
+	uint32_t c2 = __popcll(ahi & ~alo) + __popcll(bhi & ~blo);
+	uint32_t c1 = __popcll(~ahi & alo) + __popcll(~bhi & blo);
+	uint32_t c0 = (uint32_t)n - c1 - c2 - c3;
+	return c0 | c1 << 8 | c2 << 16 | c3 << 24;
+}
+
+// occ4 for one position per quad (bwt.c:169 bwt_occ4).  `p` must be uniform inside the quad.
+// All four lanes of the quad receive cnt[0..3].  `live` = false skips the load (result unspecified).
+__device__ __forceinline__ void quad_occ4(const DevIndex &ix, uint64_t p, bool live, uint64_t cnt[4])
+{
+	const int r = lane_id() & 3;
+	const bool none = (p == ~0ull);                          // bwt.c:173
+	uint64_t pp = p - (p >= ix.primary);                     // '$' is not stored (bwt.c:177)
+	uint4 v = make_uint4(0, 0, 0, 0);
+	if (live && !none) v = ix.bwt[(pp >> 7) * 4 + r];
+	int o = (int)(pp & 127) + 1;                             // bases 0..o-1 of the block are counted
+	int n = r == 2 ? (o < 64 ? o : 64) : r == 3 ? (o > 64 ? o - 64 : 0) : 0;
+	uint32_t packed = r >= 2 ? count_bases64(v, n) : 0u;
+	packed += quad_xor1(packed);
+	packed += quad_xor2(packed);                             // <=128 per byte: no carry between bytes
+	uint64_t a = (uint64_t)v.y << 32 | v.x, b = (uint64_t)v.w << 32 | v.z;
+	cnt[0] = quad_bcast64<0>(a) + (packed & 0xff);
+	cnt[1] = quad_bcast64<0>(b) + (packed >> 8 & 0xff);
+	cnt[2] = quad_bcast64<1>(a) + (packed >> 16 & 0xff);
+	cnt[3] = quad_bcast64<1>(b) + (packed >> 24);
+	if (none) cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+}
+
+struct Bi { uint64_t x0, x1, x2; };                          // bi-interval without `info`
+
+// Selects without dynamic indexing (dynamic indexing of kernel-argument arrays or local arrays would
+// send them to scratch memory).
+__device__ __forceinline__ uint64_t sel4(int c, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3)
+{
+	return c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
+}
+__device__ __forceinline__ uint64_t L2_at(const DevIndex &ix, int c)      // c in 0..4
+{
+	return c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : c == 3 ? ix.L2[3] : ix.L2[4];
+}
+__device__ __forceinline__ void set_intv(const DevIndex &ix, int b, Bi &ik)   // bwt_set_intv, bwt.h:82
+{
+	ik.x0 = L2_at(ix, b) + 1; ik.x2 = L2_at(ix, b + 1) - L2_at(ix, b); ik.x1 = L2_at(ix, 3 - b) + 1;
+}
+
+// bwt_extend (bwt.c:262) by an 8-lane group: quad 0 fetches the block of k, quad 1 the block of l.
+// `ik`, `is_back`, `live` must be uniform inside the 8-lane group; every lane receives ok[0..3].
+// Returns the number of distinct Occ blocks the reference would touch for this call (1 or 2; 0 if !live).
+__device__ __forceinline__ int group8_extend(const DevIndex &ix, const Bi &ik, int is_back, bool live, Bi ok[4])
+{
+	const int quad = (lane_id() >> 2) & 1;
+	uint64_t xa = is_back ? ik.x0 : ik.x1;                   // x[!is_back]
+	uint64_t xb = is_back ? ik.x1 : ik.x0;                   // x[is_back]
+	uint64_t k = xa - 1, l = k + ik.x2;
+	uint64_t mine[4], other[4];
+	quad_occ4(ix, quad ? l : k, live, mine);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) other[i] = half_mirror64(mine[i]);
+	uint64_t sz[4], lo[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		uint64_t tk = quad ? other[i] : mine[i], tl = quad ? mine[i] : other[i];
+		lo[i] = ix.L2[i] + 1 + tk;
+		sz[i] = tl - tk;
+	}
+	uint64_t b3 = xb + (xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary);
+	uint64_t b2 = b3 + sz[3], b1 = b2 + sz[2], b0 = b1 + sz[1];
+	uint64_t bb[4] = { b0, b1, b2, b3 };
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		ok[i].x0 = is_back ? lo[i] : bb[i];
+		ok[i].x1 = is_back ? bb[i] : lo[i];
+		ok[i].x2 = sz[i];
+	}
+	if (!live) return 0;
+	uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;   // bwt.c:194
+}
+
+// Same, but returns only ok[c] (c uniform inside the group, known before the call in every SMEM state).
+__device__ __forceinline__ int group8_extend_c(const DevIndex &ix, const Bi &ik, int is_back, int c, bool live, Bi &o)
+{
+	const int quad = (lane_id() >> 2) & 1;
+	uint64_t xa = is_back ? ik.x0 : ik.x1;
+	uint64_t xb = is_back ? ik.x1 : ik.x0;
+	uint64_t k = xa - 1, l = k + ik.x2;
+	uint64_t mine[4];
+	quad_occ4(ix, quad ? l : k, live, mine);
+	uint64_t o0 = half_mirror64(mine[0]), o1 = half_mirror64(mine[1]), o2 = half_mirror64(mine[2]), o3 = half_mirror64(mine[3]);
+	uint64_t tk0 = quad ? o0 : mine[0], tk1 = quad ? o1 : mine[1], tk2 = quad ? o2 : mine[2], tk3 = quad ? o3 : mine[3];
+	uint64_t tl0 = quad ? mine[0] : o0, tl1 = quad ? mine[1] : o1, tl2 = quad ? mine[2] : o2, tl3 = quad ? mine[3] : o3;
+	uint64_t s1 = tl1 - tk1, s2 = tl2 - tk2, s3 = tl3 - tk3;
+	uint64_t lo = L2_at(ix, c) + 1 + sel4(c, tk0, tk1, tk2, tk3);
+	uint64_t sz = sel4(c, tl0 - tk0, s1, s2, s3);
+	uint64_t cum = (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+	uint64_t bb = xb + (xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) + cum;
+	o.x0 = is_back ? lo : bb;
+	o.x1 = is_back ? bb : lo;
+	o.x2 = sz;
+	if (!live) return 0;
+	uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;
+}
+
+// One LF step (bwt.c:53 bwt_invPsi) by a quad; k uniform inside the quad; all lanes get the result.
+__device__ __forceinline__ uint64_t quad_lf(const DevIndex &ix, uint64_t k)
+{
+	const int r = lane_id() & 3;
+	uint64_t pp = k - (k >= ix.primary);                     // for k != primary identical to k - (k > primary)
+	uint4 v = ix.bwt[(pp >> 7) * 4 + r];
+	int o = (int)(pp & 127);                                 // symbol at offset o; occ counts bases 0..o
+	// the symbol: word (o>>4) of the 8 packed words; lane 2 has words 0-3, lane 3 words 4-7
+	uint32_t w = (o >> 4 & 3) == 0 ? v.x : (o >> 4 & 3) == 1 ? v.y : (o >> 4 & 3) == 2 ? v.z : v.w;
+	uint32_t sym = w >> ((~o & 15) << 1) & 3;
+	uint32_t s2 = quad_bcast<2>(sym), s3 = quad_bcast<3>(sym);
+	uint32_t c = o < 64 ? s2 : s3;
+	int n = r == 2 ? (o + 1 < 64 ? o + 1 : 64) : r == 3 ? (o + 1 > 64 ? o + 1 - 64 : 0) : 0;
+	uint32_t packed = r >= 2 ? count_bases64(v, n) : 0u;
+	packed += quad_xor1(packed);
+	packed += quad_xor2(packed);
+	uint64_t a = (uint64_t)v.y << 32 | v.x, b = (uint64_t)v.w << 32 | v.z;
+	uint64_t base = c == 0 ? quad_bcast64<0>(a) : c == 1 ? quad_bcast64<0>(b) : c == 2 ? quad_bcast64<1>(a) : quad_bcast64<1>(b);
+	uint64_t x = ix.L2[c] + base + (packed >> (c << 3) & 0xff);
+	return k == ix.primary ? 0 : x;
+}

@@ -1,0 +1,135 @@
+// Host-side reader for stock `bwa index` file sets (product code; the boundary's data format).
+// Layouts: .bwt primary,L2[1..4],words (bwt.c:385-393, 443-462); .sa primary,4 skipped,sa_intv,seq_len,
+// n_sa-1 values (bwt.c:396-441); .pac (bntseq.c:314-326, read as l_pac/4+1 bytes like bwa.c:421);
+// .ann/.amb text (bntseq.c:65-94, 97-166); optional .alt list of ALT contig names (bntseq.c:178-209).
+#include "bwahip_internal.h"
+#include <errno.h>
+
+namespace {
+
+struct File {
+	FILE *fp = nullptr;
+	File(const std::string &fn, const char *mode) { fp = fopen(fn.c_str(), mode); }
+	~File() { if (fp) fclose(fp); }
+	bool read(void *p, size_t sz, size_t n) { return fread(p, sz, n, fp) == n; }
+};
+
+bool fail(const char *what, const std::string &fn)
+{
+	fprintf(stderr, "[bwahip] index: %s: %s\n", what, fn.c_str());
+	return false;
+}
+
+bool load_bwt(const std::string &prefix, bwahip_bwt_t *b)
+{
+	memset(b, 0, sizeof(*b));
+	{
+		File f(prefix + ".bwt", "rb");
+		if (!f.fp) return fail("cannot open", prefix + ".bwt");
+		fseek(f.fp, 0, SEEK_END);
+		long sz = ftell(f.fp);
+		fseek(f.fp, 0, SEEK_SET);
+		if (sz < 40 || ((sz - 40) & 3)) return fail("bad size", prefix + ".bwt");
+		b->bwt_size = (uint64_t)(sz - 40) >> 2;
+		if (!f.read(&b->primary, 8, 1) || !f.read(b->L2 + 1, 8, 4)) return fail("short read", prefix + ".bwt");
+		b->bwt = (uint32_t*)malloc(b->bwt_size * 4);
+		if (!b->bwt || !f.read(b->bwt, 4, b->bwt_size)) return fail("short read", prefix + ".bwt");
+		b->seq_len = b->L2[4];
+	}
+	{
+		File f(prefix + ".sa", "rb");
+		uint64_t hdr[5], v[2];
+		if (!f.fp) return fail("cannot open", prefix + ".sa");
+		if (!f.read(hdr, 8, 5) || !f.read(v, 8, 2)) return fail("short read", prefix + ".sa");
+		if (hdr[0] != b->primary || v[1] != b->seq_len) return fail("SA-BWT inconsistency", prefix + ".sa");
+		b->sa_intv = (int)v[0];
+		if (b->sa_intv <= 0 || (b->sa_intv & (b->sa_intv - 1))) return fail("SA interval is not a power of 2", prefix + ".sa");
+		b->n_sa = (b->seq_len + b->sa_intv) / b->sa_intv;
+		b->sa = (uint64_t*)malloc(b->n_sa * 8);
+		if (!b->sa) return fail("out of memory", prefix + ".sa");
+		b->sa[0] = (uint64_t)-1;
+		if (!f.read(b->sa + 1, 8, b->n_sa - 1)) return fail("short read", prefix + ".sa");
+	}
+	return true;
+}
+
+bool load_bns(const std::string &prefix, bwahip_bns_t *bns, uint8_t **pac)
+{
+	memset(bns, 0, sizeof(*bns));
+	char buf[8192];
+	long long xx;
+	{
+		File f(prefix + ".ann", "r");
+		if (!f.fp) return fail("cannot open", prefix + ".ann");
+		if (fscanf(f.fp, "%lld%d%u", &xx, &bns->n_seqs, &bns->seed) != 3) return fail("parse error", prefix + ".ann");
+		bns->l_pac = xx;
+		bns->anns = (bwahip_ann_t*)calloc(bns->n_seqs > 0 ? bns->n_seqs : 1, sizeof(bwahip_ann_t));
+		for (int i = 0; i < bns->n_seqs; ++i) {
+			bwahip_ann_t *p = &bns->anns[i];
+			char *q = buf;
+			int c = 0;
+			if (fscanf(f.fp, "%u%8191s", &p->gi, buf) != 2) return fail("parse error", prefix + ".ann");
+			p->name = strdup(buf);
+			while (q - buf < (long)sizeof(buf) - 1 && (c = fgetc(f.fp)) != '\n' && c != EOF) *q++ = (char)c;
+			while (c != '\n' && c != EOF) c = fgetc(f.fp);
+			*q = 0;
+			p->anno = (q - buf > 1 && strcmp(buf, " (null)") != 0) ? strdup(buf + 1) : strdup("");
+			if (fscanf(f.fp, "%lld%d%d", &xx, &p->len, &p->n_ambs) != 3) return fail("parse error", prefix + ".ann");
+			p->offset = xx;
+		}
+	}
+	{
+		File f(prefix + ".amb", "r");
+		int n_seqs;
+		if (!f.fp) return fail("cannot open", prefix + ".amb");
+		if (fscanf(f.fp, "%lld%d%d", &xx, &n_seqs, &bns->n_holes) != 3) return fail("parse error", prefix + ".amb");
+		if (xx != bns->l_pac || n_seqs != bns->n_seqs) return fail("inconsistent with .ann", prefix + ".amb");
+		bns->ambs = bns->n_holes ? (bwahip_amb_t*)calloc(bns->n_holes, sizeof(bwahip_amb_t)) : nullptr;
+		for (int i = 0; i < bns->n_holes; ++i) {
+			if (fscanf(f.fp, "%lld%d%8191s", &xx, &bns->ambs[i].len, buf) != 3) return fail("parse error", prefix + ".amb");
+			bns->ambs[i].offset = xx; bns->ambs[i].amb = buf[0];
+		}
+	}
+	{
+		File f(prefix + ".pac", "rb");
+		if (!f.fp) return fail("cannot open", prefix + ".pac");
+		*pac = (uint8_t*)calloc(bns->l_pac / 4 + 1, 1);
+		if (!*pac || !f.read(*pac, 1, bns->l_pac / 4 + 1)) return fail("short read", prefix + ".pac");
+	}
+	{
+		File f(prefix + ".alt", "r");
+		if (f.fp) {
+			while (fgets(buf, sizeof buf, f.fp)) {
+				if (buf[0] == '@') continue;
+				char *e = buf;
+				while (*e && *e != '\t' && *e != '\n' && *e != '\r') ++e;
+				*e = 0;
+				for (int i = 0; i < bns->n_seqs; ++i)
+					if (strcmp(bns->anns[i].name, buf) == 0) { bns->anns[i].is_alt = 1; break; }
+			}
+		}
+	}
+	return true;
+}
+
+} // namespace
+
+int bwahip_load_index_files(const char *prefix, HostIndex *out)
+{
+	memset(out, 0, sizeof(*out));
+	out->owned = true;
+	if (!load_bwt(prefix, &out->bwt) || !load_bns(prefix, &out->bns, &out->pac)) {
+		bwahip_free_host_index(out);
+		return BWAHIP_EIO;
+	}
+	return 0;
+}
+
+void bwahip_free_host_index(HostIndex *h)
+{
+	if (!h || !h->owned) return;
+	free(h->bwt.bwt); free(h->bwt.sa);
+	if (h->bns.anns) for (int i = 0; i < h->bns.n_seqs; ++i) { free(h->bns.anns[i].name); free(h->bns.anns[i].anno); }
+	free(h->bns.anns); free(h->bns.ambs); free(h->pac);
+	memset(h, 0, sizeof(*h));
+}

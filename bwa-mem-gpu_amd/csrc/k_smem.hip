@@ -1,0 +1,258 @@
+// K1 -- SMEM / seed-interval collection (mem_collect_intv, bwamem.c:137-185) on gfx950.
+//
+// The algorithm is a long chain of dependent bwt_extend calls (bwt.c:262), each a random 64-byte
+// gather (two when the interval straddles an Occ block).  A single read exposes almost no memory-level
+// parallelism and ~1 us of HBM latency per step must be hidden, so the kernel packs 8 reads into one
+// wavefront: a *group* of 8 lanes owns one read (one quad per Occ block, see fmi_dev.h) and runs it
+// as an explicit state machine whose every transition issues exactly one bwt_extend.  All groups of
+// a wavefront therefore reach the extend call site together and their gathers are in flight together
+// (16 x 64 B per wavefront-step).  Groups pull reads from a global work queue.
+//
+// Per-read state machine (states cite the code they restate):
+//   pass 1  bwamem.c:144-154   for x: bwt_smem1(x, min_intv=1)        FWD (bwt.c:304-320) then BWD (bwt.c:326-345)
+//   pass 2  bwamem.c:156-165   re-seed long, rare SMEMs from their middle with min_intv = occ+1
+//   pass 3  bwamem.c:167-182   bwt_seed_strategy1 (bwt.c:358): forward-only, stop at occ < max_mem_intv
+//   sort    bwamem.c:184       by info=(qbeg<<32|qend); entries with equal info are the same bi-interval
+//                              (same query substring), so any sort yields the reference's array
+// Lists prev/curr (bwt.c:293) live in a per-group HBM scratch (L2 resident); the per-call `mem`
+// vector of bwt_smem1a is not materialised: only its last start coordinate is needed (bwt.c:333).
+// Every lane of a group keeps an identical copy of the state and performs the (identical) list
+// stores itself, so each lane only ever re-reads bytes it has written: no cross-lane memory hazard.
+#include "fmi_dev.h"
+
+namespace {
+
+constexpr int G = 8;
+enum : int { ST_IDLE = 0, ST_NEXT, ST_FWD, ST_BWD, ST_FWD3, ST_FINISH };
+
+__device__ __forceinline__ void put(DevIntv *p, uint64_t x0, uint64_t x1, uint64_t x2, uint64_t info)
+{
+	ulonglong2 *q = reinterpret_cast<ulonglong2*>(p);
+	q[0] = make_ulonglong2(x0, x1);
+	q[1] = make_ulonglong2(x2, info);
+}
+__device__ __forceinline__ void get(const DevIntv *p, uint64_t &x0, uint64_t &x1, uint64_t &x2, uint64_t &info)
+{
+	const ulonglong2 *q = reinterpret_cast<const ulonglong2*>(p);
+	ulonglong2 a = q[0], b = q[1];
+	x0 = a.x; x1 = a.y; x2 = b.x; info = b.y;
+}
+
+// NB: every access to list entries goes through put/get/get_info/get_x2 (one access path, one type):
+// mixing these vector accesses with DevIntv member loads lets type-based alias analysis reorder them.
+__device__ __forceinline__ uint64_t get_info(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].y; }
+__device__ __forceinline__ uint64_t get_x2(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].x; }
+
+__global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
+{
+	const int lane = lane_id();
+	const int gl = lane & (G - 1);
+	const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) / G);
+	const DevIndex &ix = a.ix;
+	const int min_seed_len = a.opt.min_seed_len, cap = a.cap, lcap = a.lcap;
+
+	DevIntv *const lists = a.scratch + (size_t)group * (2 * (size_t)lcap + cap);
+	DevIntv *const U = lists + 2 * (size_t)lcap;             // unsorted accumulated intervals of the read
+
+	// ---- per-group state (identical in every lane of the group; plain scalars so it stays in registers) ----
+	int st = ST_IDLE, rd = -1, len = 0, pass = 0;
+	const uint8_t *q = nullptr;
+	int x = 0, i = 0, j = 0, c = 0, min_intv = 1, ret = 0, p2k = 0, old_n = 0, out_n = 0;
+	int prev_n = 0, curr_n = 0, prev_buf = 0, prev_rev = 0, mem_n = 0, mem_last_start = 0;
+	uint64_t curr_last_x2 = 0, p_info = 0;
+	Bi ik = { 0, 0, 0 };
+	uint32_t ik_end = 0, last_push_end = 0;
+	int guard = 0;
+	bool exhausted = false;
+	unsigned long long n_ext = 0, n_blk = 0, n_out = 0;
+
+#define PREV_AT(jj) (lists + (size_t)prev_buf * lcap + (prev_rev ? prev_n - 1 - (jj) : (jj)))
+#define CURR_PUSH(X0, X1, X2, INFO) do { \
+		put(lists + (size_t)(prev_buf ^ 1) * lcap + curr_n, (X0), (X1), (X2), (INFO)); \
+		++curr_n; curr_last_x2 = (X2); } while (0)
+	// kv_push(a->mem, ...) of bwamem.c:151,164,174
+#define EMIT(X0, X1, X2, INFO) do { if (out_n < cap) put(U + out_n, (X0), (X1), (X2), (INFO)); ++out_n; } while (0)
+	// a MEM ends at start coordinate START (bwt.c:332-336); only those >= min_seed_len are kept (bwamem.c:150,163)
+#define FOUND_MEM(X0, X1, X2, FWD_END, START) do { \
+		if (mem_n == 0 || (START) < mem_last_start) { \
+			++mem_n; mem_last_start = (START); \
+			if ((int)(uint32_t)(FWD_END) - (START) >= min_seed_len) EMIT((X0), (X1), (X2), (uint64_t)(START) << 32 | (uint32_t)(FWD_END)); \
+		} } while (0)
+#define BASE_AT(p) (((p) < 0 || q[(p)] > 3) ? -1 : (int)q[(p)])
+	// bwt.c:289-303: start bwt_smem1a(X_, MI)
+#define START_SMEM(X_, MI) do { \
+		x = (X_); min_intv = (MI) < 1 ? 1 : (MI); \
+		mem_n = 0; curr_n = 0; prev_buf = 0; curr_last_x2 = 0; \
+		set_intv(ix, q[x], ik); ik_end = (uint32_t)(x + 1); i = x + 1; st = ST_FWD; } while (0)
+	// bwt.c:321-324: curr reversed becomes prev; its first entry is the last one pushed
+#define FWD_FINISH() do { \
+		ret = (int)last_push_end; \
+		prev_buf ^= 1; prev_n = curr_n; prev_rev = 1; curr_n = 0; \
+		i = x - 1; j = 0; c = BASE_AT(i); st = ST_BWD; } while (0)
+	// bwt.c:343 break; pass 1 continues at the forward end (bwamem.c:146)
+#define BWD_FINISH() do { st = ST_NEXT; if (pass == 1) x = ret; } while (0)
+
+	for (;;) {
+		// ---------------------------------------------------------------- fetch work
+		if (st == ST_IDLE && !exhausted) {
+			unsigned t = 0;
+			if (gl == 0) t = atomicAdd(a.queue, 1u);
+			t = __shfl(t, lane & ~(G - 1));
+			if (t >= (unsigned)a.n_reads) exhausted = true;
+			else {
+				rd = (int)t; q = a.seq + a.off[t]; len = (int)(a.off[t + 1] - a.off[t]);
+				out_n = 0; pass = 1; x = 0; guard = 0;
+				st = len < min_seed_len ? ST_FINISH : ST_NEXT;   // bwamem.c:267
+			}
+		}
+		if (__ballot(st != ST_IDLE) == 0) break;               // the whole wavefront is out of work
+
+		// ---------------------------------------------------------------- run to the next bwt_extend
+		bool need = false; int is_back = 0, cb = 0; Bi req = { 0, 0, 0 };
+		for (int spin = 0; spin < 8192 && !need && st != ST_IDLE; ++spin) {
+			if (st == ST_NEXT) {
+				if (pass == 1) {
+					while (x < len && q[x] > 3) ++x;              // bwamem.c:145,154
+					if (x < len) START_SMEM(x, 1);
+					else { pass = 2; old_n = out_n < cap ? out_n : cap; p2k = 0; }
+				} else if (pass == 2) {
+					bool started = false;
+					while (p2k < old_n && !started) {
+						uint64_t x0, x1, x2, info;
+						get(U + p2k, x0, x1, x2, info); ++p2k;
+						int b = (int)(info >> 32), e = (int)(uint32_t)info;
+						if (e - b < a.opt.split_len || x2 > (uint64_t)a.opt.split_width) continue;   // bwamem.c:160
+						if (q[(b + e) >> 1] > 3) continue;        // bwt.c:296 (cannot happen inside an exact match)
+						START_SMEM((b + e) >> 1, (int)x2 + 1);
+						started = true;
+					}
+					if (!started) { pass = 3; x = 0; if (a.opt.max_mem_intv <= 0) st = ST_FINISH; }
+				} else {
+					while (x < len && q[x] > 3) ++x;              // bwamem.c:170,181
+					if (x < len) { set_intv(ix, q[x], ik); i = x + 1; st = ST_FWD3; }
+					else st = ST_FINISH;
+				}
+			} else if (st == ST_FWD) {
+				if (i < len && q[i] < 4) { need = true; is_back = 0; req = ik; cb = 3 - q[i]; }
+				else {                                           // end of read / ambiguous base (bwt.c:316-320)
+					CURR_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
+					FWD_FINISH();
+				}
+			} else if (st == ST_BWD) {
+				if (c < 0) {                                     // read start or ambiguous base: every prev[] ends here
+					for (int jj = 0; jj < prev_n; ++jj) {
+						uint64_t x0, x1, x2, info;
+						get(PREV_AT(jj), x0, x1, x2, info);
+						FOUND_MEM(x0, x1, x2, info, i + 1);
+					}
+					BWD_FINISH();
+				} else {
+					get(PREV_AT(j), req.x0, req.x1, req.x2, p_info);
+					need = true; is_back = 1; cb = c;
+				}
+			} else if (st == ST_FWD3) {
+				if (i < len && q[i] < 4) { need = true; is_back = 0; req = ik; cb = 3 - q[i]; }
+				else { x = i < len ? i + 1 : len; st = ST_NEXT; }   // bwt.c:376-378
+			} else if (st == ST_FINISH) {
+				// sort by info (bwamem.c:184) with a rank sort and write the read's interval list
+				int n = out_n < cap ? out_n : cap, n_seed = 0;
+				DevIntv *dst = a.out + (size_t)rd * cap;
+				for (int t = gl; t < n; t += G) {
+					uint64_t x0, x1, x2, info;
+					get(U + t, x0, x1, x2, info);
+					int rank = 0;
+					for (int u = 0; u < n; ++u) {
+						uint64_t ku = get_info(U + u);
+						rank += (ku < info) || (ku == info && u < t);
+					}
+					put(dst + rank, x0, x1, x2, info);
+				}
+				for (int t = 0; t < n; ++t) {                   // number of SA look-ups chaining will make (bwamem.c:285-286)
+					uint64_t x2 = get_x2(U + t);
+					uint64_t step = x2 > (uint64_t)a.opt.max_occ ? x2 / a.opt.max_occ : 1;
+					uint64_t cnt = (x2 + step - 1) / step;
+					n_seed += (int)(cnt < (uint64_t)a.opt.max_occ ? cnt : (uint64_t)a.opt.max_occ);
+				}
+				if (gl == 0) {
+					a.out_n[rd] = out_n;                         // > cap tells the host to re-run with more room
+					a.seed_cnt[rd] = out_n > cap ? 0 : n_seed;
+					n_out += n;
+				}
+				st = ST_IDLE; rd = -1;
+			}
+		}
+
+		// ---------------------------------------------------------------- the one convergent bwt_extend
+		Bi o;
+		bool live = need && !(st == ST_FWD3 && ik.x2 == 0);     // an empty interval stays empty: no gather needed
+		int nb = group8_extend_c(ix, req, is_back, cb, live, o);
+		if (need && gl == 0) { ++n_ext; n_blk += nb; }
+
+		// ---------------------------------------------------------------- consume the result
+		if (need) {
+			if (++guard > 64 * BWAHIP_MAX_READ_LEN) {              // cannot happen; guarantees the grid drains
+				if (gl == 0) atomicExch(a.err, 1);
+				out_n = 0; st = ST_FINISH;
+			} else if (st == ST_FWD) {                             // bwt.c:308-315
+				bool stop = false;
+				if (o.x2 != ik.x2) {
+					CURR_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
+					if (o.x2 < (uint64_t)min_intv) stop = true;
+				}
+				if (stop) FWD_FINISH();
+				else { ik = o; ik_end = (uint32_t)(i + 1); ++i; }
+			} else if (st == ST_BWD) {                             // bwt.c:328-342
+				if (o.x2 < (uint64_t)min_intv) {
+					if (curr_n == 0) FOUND_MEM(req.x0, req.x1, req.x2, p_info, i + 1);
+				} else if (curr_n == 0 || o.x2 != curr_last_x2) {
+					CURR_PUSH(o.x0, o.x1, o.x2, p_info);
+				}
+				if (++j == prev_n) {
+					if (curr_n == 0) BWD_FINISH();
+					else {
+						prev_buf ^= 1; prev_n = curr_n; prev_rev = 0; curr_n = 0;
+						--i; j = 0; c = BASE_AT(i);
+					}
+				}
+			} else if (st == ST_FWD3) {                            // bwt.c:366-375
+				if (o.x2 < (uint64_t)a.opt.max_mem_intv && i - x >= min_seed_len) {
+					if (o.x2 > 0) EMIT(o.x0, o.x1, o.x2, (uint64_t)x << 32 | (uint32_t)(i + 1));   // bwamem.c:174
+					x = i + 1; st = ST_NEXT;
+				} else { ik = o; ++i; }
+			}
+		}
+	}
+	if (gl == 0 && (n_ext | n_out)) {
+		atomicAdd(&a.counters[CNT_EXTEND], n_ext);
+		atomicAdd(&a.counters[CNT_BLOCKS], n_blk);
+		atomicAdd(&a.counters[CNT_INTV], n_out);
+	}
+#undef PREV_AT
+#undef CURR_PUSH
+#undef EMIT
+#undef FOUND_MEM
+#undef BASE_AT
+#undef START_SMEM
+#undef FWD_FINISH
+#undef BWD_FINISH
+}
+
+} // namespace
+
+int smem_default_groups(int)
+{
+	int dev = 0, cus = 256;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+	// 8 waves per SIMD x 4 SIMDs = 32 waves (8 workgroups of 256) per CU, 8 groups per wave
+	return cus * 32 * (64 / G);
+}
+
+int launch_smem(const SmemLaunch &a, int, hipStream_t st)
+{
+	int groups = a.groups_total;
+	int blocks = groups / (256 / G);
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(k_smem, dim3(blocks), dim3(256), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}

@@ -1,0 +1,408 @@
+// Host runtime of libbwahip: context, HBM residency of the index, batch buffers, kernel sequencing
+// and the C ABI of include/bwahip.h.  One context drives one GPU from one host thread; multi-GPU
+// runs use one process (one context) per GPU and shard whole batches (DESIGN.md section "Multi-GPU").
+#include "bwahip_internal.h"
+#include <math.h>
+#include <algorithm>
+
+// ------------------------------------------------------------------ small device helpers
+struct DevBuf {
+	void *p = nullptr; size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap) return 0;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = bytes + bytes / 8 + 256;
+		if (hipMalloc(&p, want) != hipSuccess) { fprintf(stderr, "[bwahip] hipMalloc(%zu) failed\n", want); return BWAHIP_ENOMEM; }
+		cap = want;
+		return 0;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T*)p; }
+};
+
+namespace {
+// exclusive scan int32 -> int64 (n+1 outputs), one workgroup; n is at most a few million per batch
+__global__ __launch_bounds__(1024) void k_scan(const int *in, int64_t *out, int n)
+{
+	__shared__ long long part[1024];
+	const int t = threadIdx.x, per = (n + 1023) / 1024;
+	const int b = t * per, e = b + per < n ? b + per : n;
+	long long s = 0;
+	for (int i = b; i < e; ++i) s += in[i];
+	part[t] = s;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {
+		long long v = t >= d ? part[t - d] : 0;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	long long run = part[t] - s;
+	for (int i = b; i < e; ++i) { out[i] = run; run += in[i]; }
+	if (t == 1023) out[n] = part[1023];
+}
+} // namespace
+
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds" };
+
+struct bwahip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	HostIndex host;                      // host copy (owned when loaded from files)
+	DevIndex ix;
+	DevBuf d_bwt, d_sa, d_pac, d_anns;
+	// batch state
+	int n_reads = 0, max_len = 0;
+	int64_t total_bases = 0;
+	DevBuf d_seq, d_off;
+	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
+	DevBuf d_misc;                       // [0..15] counters (u64), then queue (u32), err (i32)
+	int intv_cap = 96;
+	int64_t total_seeds = 0;
+	hipEvent_t ev[8];
+	float last_ms[8];
+};
+
+DevOpt make_dev_opt(const bwahip_opt_t *o)
+{
+	DevOpt d;
+	memset(&d, 0, sizeof d);
+	d.a = o->a; d.b = o->b; d.o_del = o->o_del; d.e_del = o->e_del; d.o_ins = o->o_ins; d.e_ins = o->e_ins;
+	d.pen_clip5 = o->pen_clip5; d.pen_clip3 = o->pen_clip3; d.w = o->w; d.zdrop = o->zdrop;
+	d.min_seed_len = o->min_seed_len; d.split_width = o->split_width; d.max_occ = o->max_occ;
+	d.max_chain_gap = o->max_chain_gap; d.max_mem_intv = (int)o->max_mem_intv;
+	d.split_len = (int)(o->min_seed_len * o->split_factor + .499);          // bwamem.c:141
+	d.min_chain_weight = o->min_chain_weight; d.max_chain_extend = o->max_chain_extend;
+	d.mask_level = o->mask_level; d.drop_ratio = o->drop_ratio; d.mask_level_redun = o->mask_level_redun;
+	memcpy(d.mat, o->mat, 25);
+	return d;
+}
+
+extern "C" {
+
+const char *bwahip_version(void) { return "bwahip 0.1 (gfx950)"; }
+
+void bwahip_opt_init(bwahip_opt_t *o)        // mem_opt_init, bwamem.c:74-110
+{
+	memset(o, 0, sizeof(*o));
+	o->a = 1; o->b = 4;
+	o->o_del = o->o_ins = 6;
+	o->e_del = o->e_ins = 1;
+	o->w = 100; o->T = 30; o->zdrop = 100;
+	o->pen_unpaired = 17;
+	o->pen_clip5 = o->pen_clip3 = 5;
+	o->max_mem_intv = 20;
+	o->min_seed_len = 19; o->split_width = 10; o->max_occ = 500;
+	o->max_chain_gap = 10000; o->max_ins = 10000;
+	o->mask_level = 0.50f; o->drop_ratio = 0.50f; o->XA_drop_ratio = 0.80f;
+	o->split_factor = 1.5f;
+	o->chunk_size = 30000000;               // the fork's value (bwamem.c:99)
+	o->n_threads = 1;
+	o->max_XA_hits = 5; o->max_XA_hits_alt = 200;
+	o->max_matesw = 50;
+	o->mask_level_redun = 0.95f;
+	o->min_chain_weight = 0;
+	o->max_chain_extend = 1 << 30;
+	o->mapQ_coef_len = 50; o->mapQ_coef_fac = (int)log(o->mapQ_coef_len);
+	for (int i = 0, k = 0; i < 5; ++i)       // bwa_fill_scmat, bwa.c:249
+		for (int j = 0; j < 5; ++j) o->mat[k++] = (i == 4 || j == 4) ? -1 : i == j ? o->a : -o->b;
+}
+
+static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
+{
+	int rc = b.ensure(bytes ? bytes : 16);
+	if (rc) return rc;
+	if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+	return 0;
+}
+
+static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac)
+{
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+	int rc;
+	if ((rc = upload(c->d_bwt, bwt->bwt, bwt->bwt_size * 4, c->stream))) return rc;
+	if ((rc = upload(c->d_sa, bwt->sa, bwt->n_sa * 8, c->stream))) return rc;
+	if ((rc = upload(c->d_pac, pac, (size_t)bns->l_pac / 4 + 1, c->stream))) return rc;
+	std::vector<DevAnn> anns(bns->n_seqs);
+	for (int i = 0; i < bns->n_seqs; ++i) anns[i] = { bns->anns[i].offset, bns->anns[i].len, bns->anns[i].is_alt };
+	if ((rc = upload(c->d_anns, anns.data(), anns.size() * sizeof(DevAnn), c->stream))) return rc;
+	if ((rc = c->d_misc.ensure(1024))) return rc;
+	HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 1024, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	DevIndex &ix = c->ix;
+	memset(&ix, 0, sizeof ix);
+	ix.bwt = c->d_bwt.as<uint4>(); ix.sa = c->d_sa.as<uint64_t>(); ix.pac = c->d_pac.as<uint8_t>(); ix.anns = c->d_anns.as<DevAnn>();
+	ix.primary = bwt->primary; memcpy(ix.L2, bwt->L2, sizeof ix.L2); ix.seq_len = bwt->seq_len; ix.n_sa = bwt->n_sa;
+	ix.l_pac = bns->l_pac; ix.sa_intv = bwt->sa_intv; ix.n_seqs = bns->n_seqs;
+	for (ix.sa_shift = 0; (1 << ix.sa_shift) < bwt->sa_intv; ++ix.sa_shift);
+	if ((1 << ix.sa_shift) != bwt->sa_intv) return BWAHIP_EINVAL;
+	if (bwt->bwt_size < ((bwt->seq_len + 127) / 128) * 16) return BWAHIP_EINVAL;   // every 128-base block must be present
+	return 0;
+}
+
+int bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, int device, bwahip_ctx **out)
+{
+	if (!bwt || !bns || !pac || !out || !bwt->bwt || !bwt->sa) return BWAHIP_EINVAL;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+		fprintf(stderr, "[bwahip] no usable HIP device (requested %d of %d)\n", device, n_dev);
+		return BWAHIP_ENODEV;
+	}
+	bwahip_ctx *c = new bwahip_ctx();
+	memset(&c->host, 0, sizeof c->host);
+	c->device = device;
+	c->host.bwt = *bwt; c->host.bns = *bns; c->host.pac = (uint8_t*)pac; c->host.owned = false;
+	int rc = ctx_setup(c, bwt, bns, pac);
+	if (rc) { bwahip_destroy(c); return rc; }
+	*out = c;
+	return 0;
+}
+
+int bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out)
+{
+	if (!prefix || !out) return BWAHIP_EINVAL;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+		fprintf(stderr, "[bwahip] no usable HIP device (requested %d of %d)\n", device, n_dev);
+		return BWAHIP_ENODEV;
+	}
+	bwahip_ctx *c = new bwahip_ctx();
+	c->device = device;
+	int rc = bwahip_load_index_files(prefix, &c->host);
+	if (!rc) rc = ctx_setup(c, &c->host.bwt, &c->host.bns, c->host.pac);
+	if (rc) { bwahip_destroy(c); return rc; }
+	*out = c;
+	return 0;
+}
+
+void bwahip_destroy(bwahip_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc };
+	for (DevBuf *b : bufs) b->release();
+	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	bwahip_free_host_index(&c->host);
+	delete c;
+}
+
+const bwahip_bns_t *bwahip_bns(const bwahip_ctx *c) { return c ? &c->host.bns : nullptr; }
+const bwahip_bwt_t *bwahip_bwt(const bwahip_ctx *c) { return c ? &c->host.bwt : nullptr; }
+const uint8_t *bwahip_pac(const bwahip_ctx *c) { return c ? c->host.pac : nullptr; }
+
+// ------------------------------------------------------------------ known-answer helpers
+int bwahip_kat_occ4(bwahip_ctx *c, int n, const uint64_t *k, uint64_t *out)
+{
+	if (!c || n < 0) return BWAHIP_EINVAL;
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(c->device));
+	DevBuf dk, dout; int rc;
+	if ((rc = upload(dk, k, (size_t)n * 8, c->stream)) || (rc = dout.ensure((size_t)n * 32))) { dk.release(); dout.release(); return rc; }
+	rc = launch_kat_occ4(c->ix, n, dk.as<uint64_t>(), dout.as<uint64_t>(), c->stream);
+	if (!rc && hipMemcpyAsync(out, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	dk.release(); dout.release();
+	return rc;
+}
+
+int bwahip_kat_sa(bwahip_ctx *c, int n, const uint64_t *k, uint64_t *out)
+{
+	if (!c || n < 0) return BWAHIP_EINVAL;
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(c->device));
+	DevBuf dk, dout; int rc;
+	if ((rc = upload(dk, k, (size_t)n * 8, c->stream)) || (rc = dout.ensure((size_t)n * 8))) { dk.release(); dout.release(); return rc; }
+	rc = launch_kat_sa(c->ix, n, dk.as<uint64_t>(), dout.as<uint64_t>(), c->stream);
+	if (!rc && hipMemcpyAsync(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	dk.release(); dout.release();
+	return rc;
+}
+
+int bwahip_kat_extend(bwahip_ctx *c, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12)
+{
+	if (!c || n < 0) return BWAHIP_EINVAL;
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(c->device));
+	DevBuf dk, db, dout; int rc;
+	if ((rc = upload(dk, ik3, (size_t)n * 24, c->stream)) || (rc = upload(db, is_back, (size_t)n * 4, c->stream)) || (rc = dout.ensure((size_t)n * 96))) {
+		dk.release(); db.release(); dout.release(); return rc;
+	}
+	rc = launch_kat_extend(c->ix, n, dk.as<uint64_t>(), db.as<int>(), dout.as<uint64_t>(), c->stream);
+	if (!rc && hipMemcpyAsync(ok12, dout.p, (size_t)n * 96, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	dk.release(); db.release(); dout.release();
+	return rc;
+}
+
+// ------------------------------------------------------------------ device-resident batch
+int bwahip_batch_upload(bwahip_ctx *c, int n, const uint8_t *seq, const int64_t *off)
+{
+	if (!c || n < 0 || (n && (!seq || !off))) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	int max_len = 0;
+	for (int i = 0; i < n; ++i) {
+		int64_t l = off[i + 1] - off[i];
+		if (l < 0) return BWAHIP_EINVAL;
+		if (l > BWAHIP_MAX_READ_LEN) { fprintf(stderr, "[bwahip] read %d is %lld bases long (limit %d)\n", i, (long long)l, BWAHIP_MAX_READ_LEN); return BWAHIP_ECAPACITY; }
+		if (l > max_len) max_len = (int)l;
+	}
+	c->n_reads = n; c->max_len = max_len; c->total_bases = n ? off[n] - off[0] : 0;
+	int rc;
+	if (n && off[0] != 0) return BWAHIP_EINVAL;
+	if ((rc = upload(c->d_seq, seq, (size_t)c->total_bases, c->stream))) return rc;
+	if ((rc = upload(c->d_off, off, (size_t)(n + 1) * 8, c->stream))) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int bwahip_n_kernels(void) { return (int)(sizeof(g_kernel_names) / sizeof(g_kernel_names[0])); }
+const char *bwahip_kernel_name(int i) { return i >= 0 && i < bwahip_n_kernels() ? g_kernel_names[i] : ""; }
+
+static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed)
+{
+	const int n = c->n_reads;
+	if (n == 0) return 0;
+	DevOpt dopt = make_dev_opt(opt);
+	unsigned long long *counters = c->d_misc.as<unsigned long long>();
+	unsigned int *queue = (unsigned int*)(counters + CNT_N);
+	int *err = (int*)(queue + 4);
+	int rc;
+	for (int attempt = 0; attempt < 8; ++attempt) {
+		const int cap = c->intv_cap, lcap = c->max_len + 2;
+		const int groups = smem_default_groups(8);
+		if ((rc = c->d_intv.ensure((size_t)n * cap * sizeof(DevIntv)))) return rc;
+		if ((rc = c->d_intv_n.ensure((size_t)n * 4)) || (rc = c->d_seed_cnt.ensure((size_t)n * 4)) || (rc = c->d_lrep.ensure((size_t)n * 4))) return rc;
+		if ((rc = c->d_seed_base.ensure((size_t)(n + 1) * 8))) return rc;
+		if ((rc = c->d_scratch.ensure((size_t)groups * (2 * (size_t)lcap + cap) * sizeof(DevIntv)))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 1024, c->stream));
+		SmemLaunch sl;
+		memset(&sl, 0, sizeof sl);
+		sl.ix = c->ix; sl.opt = dopt; sl.n_reads = n; sl.seq = c->d_seq.as<uint8_t>(); sl.off = c->d_off.as<int64_t>();
+		sl.out = c->d_intv.as<DevIntv>(); sl.out_n = c->d_intv_n.as<int>(); sl.cap = cap;
+		sl.seed_cnt = c->d_seed_cnt.as<int>(); sl.l_rep = c->d_lrep.as<int>();
+		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
+		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+		if ((rc = launch_smem(sl, 8, c->stream))) return rc;
+		if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n);
+		if (timed) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+		// the number of seeds sizes the next buffers: one 8-byte read-back per batch
+		int64_t total = 0; int h_err = 0;
+		HIP_TRY(hipMemcpyAsync(&total, c->d_seed_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (h_err) { fprintf(stderr, "[bwahip] k_smem reported an internal inconsistency\n"); return BWAHIP_EINTERNAL; }
+		// interval-list overflow: the kernel stores the true count; re-run the batch with more room (GPU only, no CPU path)
+		std::vector<int> h_n(n);
+		HIP_TRY(hipMemcpy(h_n.data(), c->d_intv_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		int worst = 0;
+		for (int i = 0; i < n; ++i) worst = std::max(worst, h_n[i]);
+		if (worst > cap) { c->intv_cap = worst + 16; continue; }
+		c->total_seeds = total;
+		if ((rc = c->d_seeds.ensure((size_t)(total ? total : 1) * sizeof(DevSeed)))) return rc;
+		SeedLaunch se;
+		memset(&se, 0, sizeof se);
+		se.ix = c->ix; se.opt = dopt; se.n_reads = n; se.off = c->d_off.as<int64_t>();
+		se.intv = c->d_intv.as<DevIntv>(); se.intv_n = c->d_intv_n.as<int>(); se.cap = cap;
+		se.seed_base = c->d_seed_base.as<int64_t>(); se.seeds = c->d_seeds.as<DevSeed>(); se.counters = counters;
+		if (timed) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+		if ((rc = launch_seeds(se, total, c->stream))) return rc;
+		if (timed) HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (timed) {
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]));
+		}
+		return 0;
+	}
+	return BWAHIP_EINTERNAL;
+}
+
+int bwahip_batch_run(bwahip_ctx *c, const bwahip_opt_t *opt, float *kernel_ms, int n_ms)
+{
+	if (!c || !opt) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = run_pipeline(c, opt, true);
+	if (!rc && kernel_ms) for (int i = 0; i < n_ms && i < bwahip_n_kernels(); ++i) kernel_ms[i] = c->last_ms[i];
+	return rc;
+}
+
+int bwahip_batch_counters(bwahip_ctx *c, uint64_t *counters, int n)
+{
+	if (!c || !counters || n < 0) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	uint64_t h[CNT_N];
+	HIP_TRY(hipMemcpy(h, c->d_misc.p, sizeof h, hipMemcpyDeviceToHost));
+	for (int i = 0; i < n; ++i) counters[i] = i < CNT_N ? h[i] : 0;
+	return 0;
+}
+
+int bwahip_batch_download(bwahip_ctx *, bwahip_alnreg_v *) { return BWAHIP_EINVAL; }   // filled in when K4/K5 land
+
+// ------------------------------------------------------------------ stage dump (i64 records)
+static void rec(std::vector<int64_t> &o, int64_t tag, const std::vector<int64_t> &v)
+{
+	o.push_back(tag); o.push_back((int64_t)v.size());
+	o.insert(o.end(), v.begin(), v.end());
+}
+
+int bwahip_run_stages(bwahip_ctx *c, const bwahip_opt_t *opt, int n, const uint8_t *seq, const int64_t *off,
+                      int stage_mask, int64_t **out, int64_t *out_len)
+{
+	if (!c || !opt || !out || !out_len) return BWAHIP_EINVAL;
+	int rc = bwahip_batch_upload(c, n, seq, off);
+	if (rc) return rc;
+	if ((rc = run_pipeline(c, opt, false))) return rc;
+	std::vector<int64_t> o;
+	std::vector<int> h_n(n ? n : 1);
+	std::vector<DevIntv> h_iv((size_t)n * c->intv_cap + 1);
+	if (n) {
+		HIP_TRY(hipMemcpy(h_n.data(), c->d_intv_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_iv.data(), c->d_intv.p, (size_t)n * c->intv_cap * sizeof(DevIntv), hipMemcpyDeviceToHost));
+	}
+	std::vector<int64_t> h_base(n + 1, 0);
+	std::vector<DevSeed> h_seeds((size_t)c->total_seeds + 1);
+	if (n) {
+		HIP_TRY(hipMemcpy(h_base.data(), c->d_seed_base.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+		if (c->total_seeds) HIP_TRY(hipMemcpy(h_seeds.data(), c->d_seeds.p, (size_t)c->total_seeds * sizeof(DevSeed), hipMemcpyDeviceToHost));
+	}
+	for (int i = 0; i < n; ++i) {
+		std::vector<int64_t> v = { (int64_t)i, off[i + 1] - off[i] };
+		rec(o, 100, v);
+		if (stage_mask & (1 << BWAHIP_STAGE_INTV)) {
+			v.clear();
+			for (int t = 0; t < h_n[i]; ++t) {
+				const DevIntv &p = h_iv[(size_t)i * c->intv_cap + t];
+				v.push_back((int64_t)p.x0); v.push_back((int64_t)p.x1); v.push_back((int64_t)p.x2); v.push_back((int64_t)p.info);
+			}
+			rec(o, BWAHIP_STAGE_INTV, v);
+		}
+		if (stage_mask & (1 << 6)) {                 // debug stage: raw seeds (rbeg,qbeg,len,rid) in look-up order
+			v.clear();
+			for (int64_t t = h_base[i]; t < h_base[i + 1]; ++t) {
+				v.push_back(h_seeds[t].rbeg); v.push_back(h_seeds[t].qbeg); v.push_back(h_seeds[t].len); v.push_back(h_seeds[t].rid);
+			}
+			rec(o, 6, v);
+		}
+	}
+	*out_len = (int64_t)o.size();
+	*out = (int64_t*)malloc(o.size() * 8 + 8);
+	if (!*out) return BWAHIP_ENOMEM;
+	memcpy(*out, o.data(), o.size() * 8);
+	return 0;
+}
+
+int bwahip_align_batch(bwahip_ctx *, const bwahip_opt_t *, int, bwahip_seq_t *, bwahip_alnreg_v *) { return BWAHIP_EINVAL; }
+int bwahip_process_seqs(bwahip_ctx *, const bwahip_opt_t *, int64_t, int, bwahip_seq_t *, const bwahip_pestat_t *) { return BWAHIP_EINVAL; }
+int bwahip_kat_ksw_extend(bwahip_ctx *, int, const int *, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *, int *) { return BWAHIP_EINVAL; }
+
+} // extern "C"

@@ -1,0 +1,224 @@
+/* bwahip.h -- C ABI of the MI355X-native BWA-MEM hot path.
+ *
+ * This is the drop-in boundary: a thin `extern "C"` launcher that replaces the
+ * reference's CUDA seam (cuda/bwamem_GPU.cuh:13 mem_align_GPU,
+ * cuda/streams.cuh:21-63 newProcess/newTransfer/..., cuda/bwt_CUDA.cuh,
+ * cuda/ksw_CUDA.cuh) behind the unchanged host surface
+ *     mem_process_seqs()   bwamem.h:69 / bwamem.c:1215
+ *     mem_align1_core()    bwamem.c:1061   (= the per-read work of worker1, bwamem.c:1183)
+ * Plain pointers and sizes only; no C++/torch types.  Every struct below is a
+ * layout mirror of the reference's own struct (cited), so a reference
+ * translation unit can pass its objects straight through.
+ * All functions return 0 on success and a negative BWAHIP_E* code on failure;
+ * nothing here ever falls back to a CPU implementation of the hot path.
+ */
+#ifndef BWAHIP_H
+#define BWAHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- layout mirrors of reference types --------------------------------- */
+
+typedef struct {                 /* bwt_t, bwt.h:48-60 */
+	uint64_t primary;
+	uint64_t L2[5];
+	uint64_t seq_len;
+	uint64_t bwt_size;           /* number of uint32 words in `bwt` */
+	uint32_t *bwt;               /* Occ-interleaved BWT: per 128 bases 4 x u64 counts + 8 x u32 (bwtindex.c:150) */
+	uint32_t cnt_table[256];
+	int sa_intv;
+	uint64_t n_sa;
+	uint64_t *sa;
+} bwahip_bwt_t;
+
+typedef struct {                 /* bntann1_t, bntseq.h:41-48 */
+	int64_t offset;
+	int32_t len;
+	int32_t n_ambs;
+	uint32_t gi;
+	int32_t is_alt;
+	char *name, *anno;
+} bwahip_ann_t;
+
+typedef struct {                 /* bntamb1_t, bntseq.h:50-54 */
+	int64_t offset;
+	int32_t len;
+	char amb;
+} bwahip_amb_t;
+
+typedef struct {                 /* bntseq_t, bntseq.h:56-64 */
+	int64_t l_pac;
+	int32_t n_seqs;
+	uint32_t seed;
+	bwahip_ann_t *anns;
+	int32_t n_holes;
+	bwahip_amb_t *ambs;
+	FILE *fp_pac;
+} bwahip_bns_t;
+
+typedef struct {                 /* bseq1_t, bwa.h:58-63 (fork layout: l_name/l_comment/l_qual appended) */
+	int l_seq, id;
+	char *name, *comment, *seq, *qual, *sam;
+	int8_t l_name, l_comment;
+	int16_t l_qual;
+} bwahip_seq_t;
+
+typedef struct {                 /* mem_opt_t, bwa.h:86-118 (168 bytes, mat at offset 136) */
+	uint64_t max_mem_intv;
+	int a, b;
+	int o_del, e_del;
+	int o_ins, e_ins;
+	int pen_unpaired;
+	int pen_clip5, pen_clip3;
+	int w;
+	int zdrop;
+	int T;
+	int flag;
+	int min_seed_len;
+	int min_chain_weight;
+	int max_chain_extend;
+	float split_factor;
+	int split_width;
+	int max_occ;
+	int max_chain_gap;
+	int n_threads;
+	int chunk_size;
+	float mask_level;
+	float drop_ratio;
+	float XA_drop_ratio;
+	float mask_level_redun;
+	float mapQ_coef_len;
+	int mapQ_coef_fac;
+	int max_ins;
+	int max_matesw;
+	int max_XA_hits, max_XA_hits_alt;
+	int8_t mat[25];
+} bwahip_opt_t;
+
+#define BWAHIP_F_PE        0x2      /* MEM_F_* of bwa.h:70-81 */
+#define BWAHIP_F_NOPAIRING 0x4
+#define BWAHIP_F_ALL       0x8
+#define BWAHIP_F_NO_MULTI  0x10
+#define BWAHIP_F_NO_RESCUE 0x20
+#define BWAHIP_F_REF_HDR   0x100
+#define BWAHIP_F_SOFTCLIP  0x200
+#define BWAHIP_F_SMARTPE   0x400
+#define BWAHIP_F_PRIMARY5  0x800
+#define BWAHIP_F_KEEP_SUPP_MAPQ 0x1000
+#define BWAHIP_F_XB        0x2000
+
+typedef struct {                 /* mem_alnreg_t, bwa.h:145-163 (88 bytes) */
+	int64_t rb, re;
+	uint64_t hash;
+	float frac_rep;
+	int qb, qe;
+	int rid;
+	int score;
+	int truesc;
+	int sub;
+	int alt_sc;
+	int csub;
+	int sub_n;
+	int w;
+	int seedcov;
+	int secondary;
+	int secondary_all;
+	int seedlen0;
+	int n_comp:30, is_alt:2;
+} bwahip_alnreg_t;
+
+typedef struct { int n, m; bwahip_alnreg_t *a; } bwahip_alnreg_v;   /* mem_alnreg_v, bwa.h:165 */
+
+typedef struct {                 /* mem_pestat_t, bwa.h:167-171 */
+	int low, high;
+	int failed;
+	double avg, std;
+} bwahip_pestat_t;
+
+typedef struct { uint64_t x[3], info; } bwahip_intv_t;              /* bwtintv_t, bwt.h:62-64 */
+
+/* ---- error codes -------------------------------------------------------- */
+#define BWAHIP_OK          0
+#define BWAHIP_EINVAL     -1   /* bad argument */
+#define BWAHIP_ENODEV     -2   /* no usable HIP device / HIP runtime error (message on stderr) */
+#define BWAHIP_ENOMEM     -3   /* device or host allocation failed */
+#define BWAHIP_EIO        -4   /* index files unreadable / inconsistent */
+#define BWAHIP_ECAPACITY  -5   /* a read exceeds the compiled limits (length > BWAHIP_MAX_READ_LEN) */
+#define BWAHIP_EINTERNAL  -6   /* a kernel reported an inconsistency (never expected) */
+
+#define BWAHIP_MAX_READ_LEN 1000
+
+typedef struct bwahip_ctx bwahip_ctx;
+
+/* ---- lifetime ------------------------------------------------------------
+ * bwahip_init replaces newProcess()/transferIndex() (cuda/streams.cu:8,164): it copies the three
+ * index arrays (bwt, sa, pac) and the contig table into HBM of HIP device `device` and builds the
+ * launch workspaces.  The host arrays are not referenced after it returns. */
+int  bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, int device, bwahip_ctx **out);
+/* Convenience: read a stock `bwa index` file set <prefix>.{bwt,sa,pac,ann,amb[,alt]} (bwa.c:402 bwa_idx_load) and init. */
+int  bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out);
+void bwahip_destroy(bwahip_ctx *ctx);
+/* Host copies of the loaded index (valid until destroy); lets a caller that used
+ * bwahip_init_from_files get at contig names etc. without loading the index twice. */
+const bwahip_bns_t *bwahip_bns(const bwahip_ctx *ctx);
+const bwahip_bwt_t *bwahip_bwt(const bwahip_ctx *ctx);
+const uint8_t      *bwahip_pac(const bwahip_ctx *ctx);
+void bwahip_opt_init(bwahip_opt_t *opt);     /* mem_opt_init defaults, bwamem.c:74 */
+
+/* ---- the hot path ---------------------------------------------------------
+ * bwahip_align_batch == kt_for(worker1) of mem_process_seqs (bwamem.c:1232): for every read i it
+ * produces exactly the mem_alnreg_v that mem_align1_core (bwamem.c:1061) returns, computed on the
+ * GPU.  seqs[i].seq is converted in place to 0..4 codes as the reference does (bwamem.c:1067).
+ * regs_out[i].a is malloc()ed for the caller (free() it), regs_out[i].n == regs_out[i].m. */
+int bwahip_align_batch(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, bwahip_seq_t *seqs, bwahip_alnreg_v *regs_out);
+
+/* bwahip_process_seqs == mem_process_seqs (bwamem.h:69): hot path on the GPU, then the per-read
+ * finalisation (mark primary, mapQ, CIGAR/NM/MD, SAM text; PE: insert-size stats, mate rescue,
+ * pairing) with opt->n_threads host threads.  seqs[i].sam is malloc()ed, NUL terminated. */
+int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);
+
+/* ---- stage-level entry points (parity tests and bench) --------------------
+ * Reads are given packed: `seq` holds the concatenated 0..4 codes, read i is seq[off[i] .. off[i+1]).
+ * Results come back as "i64 record" streams in malloc()ed buffers (*out, *out_len int64 words) in the
+ * same layout the oracle's stage dump uses (oracle/ref_driver.c): see bwahip_stage_* tags. */
+#define BWAHIP_STAGE_INTV      1   /* intervals after mem_collect_intv (bwamem.c:137) */
+#define BWAHIP_STAGE_CHAIN     2   /* chains after mem_chain (bwamem.c:258), B-tree order */
+#define BWAHIP_STAGE_CHAIN_FLT 3   /* chains after mem_chain_flt (bwamem.c:334) */
+#define BWAHIP_STAGE_REGS_PRE  5   /* regions after all mem_chain2aln calls (bwamem.c:1079) */
+#define BWAHIP_STAGE_REGS      4   /* regions returned by mem_align1_core */
+int bwahip_run_stages(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, const uint8_t *seq, const int64_t *off,
+                      int stage_mask, int64_t **out, int64_t *out_len);
+
+/* Device-resident batch for benchmarking: upload once, run the whole hot path (seq codes in HBM ->
+ * alignment regions in HBM) any number of times.  kernel_ms (may be NULL) receives the per-kernel
+ * durations of the last run measured with HIP events on the launch stream, in launch order
+ * (see bwahip_kernel_name). */
+int bwahip_batch_upload(bwahip_ctx *ctx, int n, const uint8_t *seq, const int64_t *off);
+int bwahip_batch_run(bwahip_ctx *ctx, const bwahip_opt_t *opt, float *kernel_ms, int n_kernel_ms);
+int bwahip_batch_download(bwahip_ctx *ctx, bwahip_alnreg_v *regs_out);       /* regs of the last run */
+int bwahip_n_kernels(void);
+const char *bwahip_kernel_name(int i);
+/* Algorithmic work counters of the last bwahip_batch_run, counted on the device by the kernels
+ * themselves: [0] bwt_extend calls, [1] Occ blocks touched by them,
+ * [2] bwt_sa calls, [3] LF steps, [4] intervals written, [5] seeds, [6] DP cells. */
+int bwahip_batch_counters(bwahip_ctx *ctx, uint64_t *counters, int n);
+
+/* Known-answer helpers used by the parity tests: device Occ/extend/SA on arrays of inputs. */
+int bwahip_kat_occ4(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *cnt4_out);
+int bwahip_kat_sa(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *sa_out);
+int bwahip_kat_extend(bwahip_ctx *ctx, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12_out);
+int bwahip_kat_ksw_extend(bwahip_ctx *ctx, int n, const int *params /*n x 10*/, const uint8_t *q, const int64_t *qoff,
+                          const uint8_t *t, const int64_t *toff, int *out6 /*n x 6*/);
+
+const char *bwahip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""GPU parity tests proper: every stage boundary of mem_align1_core, HIP path (through the C ABI)
+vs the oracle on the same seeded reads.  Bit-exact (integer/index work)."""
+import os
+import numpy as np
+import pytest
+import common
+from common import bw
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(small_index):
+    c = bw.Context(small_index["prefix"])
+    yield c
+    c.close()
+
+
+def _reads(small_index, tmp_path, name, n, length, sub, indel, nn, seed, chim=0):
+    fq = str(tmp_path / f"{name}.fq")
+    bw.make_reads(small_index["fa"], fq, None, n, length, sub, indel, nn, seed, chim)
+    _, seqs, _ = bw.read_fastq(fq)
+    return fq, seqs
+
+
+@pytest.mark.parametrize("name,n,length,sub,indel,nn,seed,chim", [
+    ("se150", 3000, 150, 10000, 2000, 500, 101, 20000),
+    ("se100", 2000, 100, 10000, 0, 0, 102, 0),
+    ("se250", 1500, 250, 50000, 3000, 500, 105, 30000),
+    ("short", 500, 30, 20000, 0, 20000, 106, 0),
+])
+def test_intervals_match_oracle(ctx, small_index, tmp_path, name, n, length, sub, indel, nn, seed, chim):
+    fq, seqs = _reads(small_index, tmp_path, name, n, length, sub, indel, nn, seed, chim)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_INTV]))
+    common.assert_stage_equal(got, want, bw.STAGE_INTV, f"intervals[{name}]")
+
+
+def test_fm_known_answers_vs_oracle_lib(ctx, small_index):
+    """Device Occ / SA / extend against the oracle's C functions on random rows."""
+    import ctypes as C
+    ora = C.CDLL(os.path.join(common.ROOT, "oracle", "liboracle.so"))
+    ora.ora_index_load.restype = C.c_void_p
+    ora.ora_index_load.argtypes = [C.c_char_p]
+    idx = ora.ora_index_load(small_index["prefix"].encode())
+    fmi = C.cast(idx, C.POINTER(C.c_void_p))[0]
+    ora.ora_occ4.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    ora.ora_sa.argtypes = [C.c_void_p, C.c_uint64]
+    ora.ora_sa.restype = C.c_uint64
+    seq_len = 2 * 1000000
+    rng = np.random.default_rng(5)
+    k = np.concatenate([np.array([2**64 - 1, seq_len, 0, 1, 127, 128, 129], dtype=np.uint64),
+                        rng.integers(0, seq_len + 1, 4000, dtype=np.uint64)])
+    got = ctx.kat_occ4(k)
+    want = np.zeros_like(got)
+    buf = (C.c_uint64 * 4)()
+    for i, kk in enumerate(k):
+        ora.ora_occ4(fmi, int(kk), buf)
+        want[i] = list(buf)
+    assert np.array_equal(got, want)
+    ks = k[1:]
+    got_sa = ctx.kat_sa(ks)
+    want_sa = np.array([ora.ora_sa(fmi, int(kk)) for kk in ks], dtype=np.uint64)
+    assert np.array_equal(got_sa, want_sa)
+
+
+def test_extend_known_answers_vs_oracle_lib(ctx, small_index):
+    """bwt_extend on the device for random walks (both directions), incl. size-1 intervals."""
+    import ctypes as C
+
+    class Intv(C.Structure):
+        _fields_ = [("x", C.c_uint64 * 3), ("info", C.c_uint64)]
+    ora = C.CDLL(os.path.join(common.ROOT, "oracle", "liboracle.so"))
+    ora.ora_index_load.restype = C.c_void_p
+    ora.ora_index_load.argtypes = [C.c_char_p]
+    idx = ora.ora_index_load(small_index["prefix"].encode())
+    fmi = C.cast(idx, C.POINTER(C.c_void_p))[0]
+    ora.ora_extend.argtypes = [C.c_void_p, C.POINTER(Intv), C.POINTER(Intv), C.c_int]
+    ora.ora_set_intv.argtypes = [C.c_void_p, C.c_int, C.POINTER(Intv)]
+    rng = np.random.default_rng(7)
+    iks, backs, wants = [], [], []
+    ok = (Intv * 4)()
+    for walk in range(300):
+        ik = Intv()
+        ora.ora_set_intv(fmi, int(rng.integers(0, 4)), C.byref(ik))
+        for step in range(40):
+            if ik.x[2] == 0:
+                break
+            back = int(rng.integers(0, 2))
+            ora.ora_extend(fmi, C.byref(ik), ok, back)
+            iks.append([ik.x[0], ik.x[1], ik.x[2]])
+            backs.append(back)
+            wants.append([v for o in ok for v in (o.x[0], o.x[1], o.x[2])])
+            c = int(rng.integers(0, 4))
+            best = max(range(4), key=lambda b: ok[b].x[2]) if step % 3 else c   # mostly follow a surviving path
+            nxt = Intv()
+            nxt.x[0], nxt.x[1], nxt.x[2] = ok[best].x[0], ok[best].x[1], ok[best].x[2]
+            ik = nxt
+    got = ctx.kat_extend(np.array(iks, dtype=np.uint64), np.array(backs, dtype=np.int32))
+    want = np.array(wants, dtype=np.uint64)
+    sizes = np.array(iks, dtype=np.uint64)[:, 2]
+    assert (sizes == 1).sum() > 100
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} of {len(want)} extends differ; first: ik={iks[bad[0]]} back={backs[bad[0]]} got={got[bad[0]]} want={want[bad[0]]}"
