@@ -99,6 +99,36 @@ struct SeedLaunch {
 };
 int launch_seeds(const SeedLaunch &a, int64_t total_seeds, hipStream_t st);
 
+struct BtNodeOpaque { int w[26]; };              // sizeof(BtNode) in k_chain.hip (2 + 11 + 12 ints, padded)
+struct ChainWOpaque { int64_t pos; int a, b, c, d; };
+struct ChainLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const int64_t *off;
+	const DevIntv *intv; const int *intv_n; int cap;
+	const int64_t *seed_base; const DevSeed *seeds;
+	// per-seed-slot scratch (indexed from seed_base[r])
+	struct ChainWOpaque *cw_; int *nxt, *ord, *wts, *kept, *first, *keep_list;
+	struct BtNodeOpaque *nodes_; int *stack;     // nodes: (seed_base>>2) + 4r ; stack: 256 ints per read
+	// outputs
+	DevChain *chains; DevSeed *chain_seeds; int *chain_n, *kept_seeds;
+	// optional stage dump of the unfiltered chains (nullptr = off)
+	DevChain *dbg_chains; DevSeed *dbg_seeds; int *dbg_chain_n;
+};
+int launch_chain(const ChainLaunch &a, hipStream_t st);
+
+struct ExtLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const uint8_t *seq; const int64_t *off;
+	const int64_t *seed_base; const DevChain *chains; const DevSeed *chain_seeds; const int *chain_n;
+	const int64_t *reg_base;                     // exclusive scan of kept_seeds
+	DevReg *regs; int *reg_n;                    // final regions of read r at regs[reg_base[r] .. +reg_n[r])
+	DevReg *dbg_regs; int *dbg_reg_n;            // optional: regions before mem_sort_dedup_patch
+	DevReg *tmp_regs;                            // spare list of the same size as regs (sort gather)
+	int *srt;                                    // per-seed-slot scratch (sorted seed order), 2 ints per slot
+	unsigned long long *counters; int *err;
+};
+int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
+
 int launch_kat_occ4(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st);
 int launch_kat_sa(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st);
 int launch_kat_extend(const DevIndex &ix, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12, hipStream_t st);

@@ -1,0 +1,374 @@
+// K3 -- chaining and chain filtering (mem_chain body bwamem.c:272-317, mem_chain_flt bwamem.c:334-392).
+//
+// Both steps are short, strictly sequential per read and order-sensitive (greedy merge into the
+// chain with the greatest pos <= rbeg, found through a B-tree whose shape decides where duplicate
+// positions land, kbtree.h; then an UNSTABLE introsort by weight, ksort.h:176-227).  They are not the
+// bottleneck, so they run one read per lane, restating the sequential algorithms literally; all
+// working storage is per-read global memory sized from the seed count (no in-kernel allocation,
+// no local arrays: nothing goes to scratch).
+//   in : seeds of the read in look-up order (K2), sorted intervals (K1) for l_rep
+//   out: filtered chains in final order with their seeds contiguous; optional pre-filter dump
+#include "bwahip_internal.h"
+
+namespace {
+
+constexpr int BT_T = 6, BT_MAXK = 2 * BT_T - 1;              // kbtree.h:59 with sizeof(mem_chain_t) = 32
+
+struct BtNode { int is_internal, n; int key[BT_MAXK]; int ptr[BT_MAXK + 1]; int pad; };
+static_assert(sizeof(BtNode) == sizeof(BtNodeOpaque), "BtNode layout");
+struct ChainW { int64_t pos; int head, tail, n, rid; };      // chain under construction: seeds as a linked list
+static_assert(sizeof(ChainW) == sizeof(ChainWOpaque), "ChainW layout");
+
+struct ReadCtx {
+	const DevSeed *seeds; int n_seeds;
+	ChainW *cw; int n_chains;
+	int *nxt;
+	BtNode *nodes; int n_nodes, root;
+	int *ord, *wts, *kept, *first, *keep_list, *stack;
+};
+
+__device__ __forceinline__ int cmp_pos(int64_t a, int64_t b) { return (b < a) - (a < b); }
+
+// kbtree.h:119 __kb_getp_aux
+__device__ int bt_find(const ReadCtx &c, const BtNode *x, int64_t pos, int *r)
+{
+	int begin = 0, end = x->n;
+	if (x->n == 0) return -1;
+	while (begin < end) {
+		int mid = (begin + end) >> 1;
+		if (c.cw[x->key[mid]].pos < pos) begin = mid + 1; else end = mid;
+	}
+	if (begin == x->n) { *r = 1; return x->n - 1; }
+	*r = cmp_pos(pos, c.cw[x->key[begin]].pos);
+	if (*r < 0) --begin;
+	return begin;
+}
+
+// kbtree.h:152 kb_intervalp (lower bound only)
+__device__ int bt_lower(const ReadCtx &c, int64_t pos)
+{
+	int xi = c.root, lower = -1;
+	for (;;) {
+		const BtNode *x = &c.nodes[xi];
+		int r = 0, i = bt_find(c, x, pos, &r);
+		if (i >= 0 && r == 0) return x->key[i];
+		if (i >= 0) lower = x->key[i];
+		if (!x->is_internal) return lower;
+		xi = x->ptr[i + 1];
+	}
+}
+
+__device__ int bt_new(ReadCtx &c, int is_internal)
+{
+	BtNode *z = &c.nodes[c.n_nodes];
+	z->is_internal = is_internal; z->n = 0;
+	return c.n_nodes++;
+}
+
+// kbtree.h:172 __kb_split
+__device__ void bt_split(ReadCtx &c, int xi, int i, int yi)
+{
+	int zi = bt_new(c, c.nodes[yi].is_internal);
+	BtNode *x = &c.nodes[xi], *y = &c.nodes[yi], *z = &c.nodes[zi];
+	z->n = BT_T - 1;
+	for (int k = 0; k < BT_T - 1; ++k) z->key[k] = y->key[k + BT_T];
+	if (y->is_internal) for (int k = 0; k < BT_T; ++k) z->ptr[k] = y->ptr[k + BT_T];
+	y->n = BT_T - 1;
+	for (int k = x->n; k > i; --k) x->ptr[k + 1] = x->ptr[k];
+	x->ptr[i + 1] = zi;
+	for (int k = x->n - 1; k >= i; --k) x->key[k + 1] = x->key[k];
+	x->key[i] = y->key[BT_T - 1];
+	++x->n;
+}
+
+// kbtree.h:188-222 kb_putp (iterative descent)
+__device__ void bt_put(ReadCtx &c, int k)
+{
+	const int64_t pos = c.cw[k].pos;
+	if (c.nodes[c.root].n == BT_MAXK) {
+		int s = bt_new(c, 1);
+		c.nodes[s].ptr[0] = c.root;
+		bt_split(c, s, 0, c.root);
+		c.root = s;
+	}
+	int xi = c.root;
+	for (;;) {
+		BtNode *x = &c.nodes[xi];
+		int r = 0;
+		if (!x->is_internal) {
+			int i = bt_find(c, x, pos, &r);
+			for (int t = x->n - 1; t > i; --t) x->key[t + 1] = x->key[t];
+			x->key[i + 1] = k;
+			++x->n;
+			return;
+		}
+		int i = bt_find(c, x, pos, &r) + 1;
+		if (c.nodes[x->ptr[i]].n == BT_MAXK) {
+			bt_split(c, xi, i, x->ptr[i]);
+			x = &c.nodes[xi];
+			if (pos > c.cw[x->key[i]].pos) ++i;
+		}
+		xi = x->ptr[i];
+	}
+}
+
+// kbtree.h:336 __kb_traverse: in-order walk with an explicit stack (node, next child) in global memory
+__device__ int bt_inorder(const ReadCtx &c, int *out)
+{
+	int n_out = 0, sp = 0;
+	int *stk = c.stack;                                         // pairs (node, i)
+	stk[0] = c.root; stk[1] = 0;
+	while (sp >= 0) {
+		int xi = stk[2 * sp], i = stk[2 * sp + 1];
+		const BtNode *x = &c.nodes[xi];
+		if (x->is_internal) {
+			if (i <= x->n) {
+				if (i > 0) out[n_out++] = x->key[i - 1];
+				stk[2 * sp + 1] = i + 1;
+				++sp; stk[2 * sp] = x->ptr[i]; stk[2 * sp + 1] = 0;
+			} else --sp;
+		} else {
+			for (int t = 0; t < x->n; ++t) out[n_out++] = x->key[t];
+			--sp;
+		}
+	}
+	return n_out;
+}
+
+// bwamem.c:197 test_and_merge
+__device__ bool try_merge(ReadCtx &c, const DevOpt &opt, int64_t l_pac, int ci, int si)
+{
+	ChainW *ch = &c.cw[ci];
+	const DevSeed p = c.seeds[si], first = c.seeds[ch->head], last = c.seeds[ch->tail];
+	int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
+	if (p.rid != ch->rid) return false;
+	if (p.qbeg >= first.qbeg && p.qbeg + p.len <= qend && p.rbeg >= first.rbeg && p.rbeg + p.len <= rend) return true;
+	if ((last.rbeg < l_pac || first.rbeg < l_pac) && p.rbeg >= l_pac) return false;
+	int64_t x = p.qbeg - last.qbeg, y = p.rbeg - last.rbeg;
+	if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - last.len < opt.max_chain_gap && y - last.len < opt.max_chain_gap) {
+		c.nxt[ch->tail] = si; c.nxt[si] = -1; ch->tail = si; ++ch->n;
+		return true;
+	}
+	return false;
+}
+
+// bwamem.c:220 mem_chain_weight
+__device__ int chain_weight(const ReadCtx &c, int ci)
+{
+	int64_t end = 0;
+	int w = 0, tmp;
+	for (int s = c.cw[ci].head; s >= 0; s = c.nxt[s]) {
+		const DevSeed d = c.seeds[s];
+		if (d.qbeg >= end) w += d.len;
+		else if (d.qbeg + d.len > end) w += (int)(d.qbeg + d.len - end);
+		end = end > d.qbeg + d.len ? end : d.qbeg + d.len;
+	}
+	tmp = w; w = 0; end = 0;
+	for (int s = c.cw[ci].head; s >= 0; s = c.nxt[s]) {
+		const DevSeed d = c.seeds[s];
+		if (d.rbeg >= end) w += d.len;
+		else if (d.rbeg + d.len > end) w += (int)(d.rbeg + d.len - end);
+		end = end > d.rbeg + d.len ? end : d.rbeg + d.len;
+	}
+	w = w < tmp ? w : tmp;
+	return w < 1 << 30 ? w : (1 << 30) - 1;
+}
+
+// ---- ksort.h:146-227 on an array of chain indices, key = weight, "less" = heavier first (bwamem.c:331)
+#define W_LT(a, b) (c.wts[(a)] > c.wts[(b)])
+__device__ void isort_insertion(const ReadCtx &c, int *s, int *t)
+{
+	for (int *i = s + 1; i < t; ++i)
+		for (int *j = i; j > s && W_LT(*j, *(j - 1)); --j) { int tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+__device__ void isort_comb(const ReadCtx &c, int n, int *a)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	int swapped, gap = n;
+	do {
+		if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		swapped = 0;
+		for (int *i = a; i < a + n - gap; ++i) {
+			int *j = i + gap;
+			if (W_LT(*j, *i)) { int tmp = *i; *i = *j; *j = tmp; swapped = 1; }
+		}
+	} while (swapped || gap > 2);
+	if (gap != 1) isort_insertion(c, a, a + n);
+}
+__device__ void isort_weight(const ReadCtx &c, int n, int *a)
+{
+	int d, top = 0, *stk = c.stack;                             // frames (lo, hi, depth)
+	int *s, *t, *i, *j, *k, pivot, tmp;
+	if (n < 1) return;
+	if (n == 2) { if (W_LT(a[1], a[0])) { tmp = a[0]; a[0] = a[1]; a[1] = tmp; } return; }
+	for (d = 2; 1 << d < n; ++d);
+	s = a; t = a + (n - 1); d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { isort_comb(c, (int)(t - s) + 1, s); t = s; continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (W_LT(*k, *i)) { if (W_LT(*k, *j)) k = j; }
+			else k = W_LT(*j, *i) ? i : j;
+			pivot = *k;
+			if (k != t) { tmp = *k; *k = *t; *t = tmp; }
+			for (;;) {
+				do ++i; while (i < t && W_LT(*i, pivot));          // i stops at the pivot (at t) at the latest
+				do --j; while (i <= j && W_LT(pivot, *j));
+				if (j <= i) break;
+				tmp = *i; *i = *j; *j = tmp;
+			}
+			tmp = *i; *i = *t; *t = tmp;
+			if (i - s > t - i) {
+				if (i - s > 16) { stk[3*top] = (int)(s - a); stk[3*top+1] = (int)(i - 1 - a); stk[3*top+2] = d; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { stk[3*top] = (int)(i + 1 - a); stk[3*top+1] = (int)(t - a); stk[3*top+2] = d; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) { isort_insertion(c, a, a + n); return; }
+			--top; s = a + stk[3*top]; t = a + stk[3*top+1]; d = stk[3*top+2];
+		}
+	}
+}
+#undef W_LT
+
+__device__ __forceinline__ int chn_beg(const ReadCtx &c, int ci) { return c.seeds[c.cw[ci].head].qbeg; }
+__device__ __forceinline__ int chn_end(const ReadCtx &c, int ci) { const DevSeed d = c.seeds[c.cw[ci].tail]; return d.qbeg + d.len; }
+
+__device__ void write_chains(const ReadCtx &c, const DevIndex &ix, int n, const int *order, float frac_rep, bool with_flt,
+                             DevChain *oc, DevSeed *os)
+{
+	int so = 0;
+	for (int k = 0; k < n; ++k) {
+		int ci = order[k];
+		DevChain h;
+		h.pos = c.cw[ci].pos; h.seed_off = so; h.n = c.cw[ci].n; h.rid = c.cw[ci].rid;
+		h.w = with_flt ? c.wts[ci] : 0; h.kept = with_flt ? c.kept[ci] : 0; h.first = with_flt ? c.first[ci] : 0;
+		h.is_alt = ix.anns[h.rid].is_alt ? 1 : 0; h.frac_rep = frac_rep;
+		oc[k] = h;
+		for (int s = c.cw[ci].head; s >= 0; s = c.nxt[s]) os[so++] = c.seeds[s];
+	}
+}
+
+__global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.n_reads) return;
+	const int64_t sb = a.seed_base[r];
+	const int S = (int)(a.seed_base[r + 1] - sb), len = (int)(a.off[r + 1] - a.off[r]);
+	ReadCtx c;
+	c.seeds = a.seeds + sb; c.n_seeds = S;
+	c.cw = reinterpret_cast<ChainW*>(a.cw_) + sb; c.nxt = a.nxt + sb; c.ord = a.ord + sb; c.wts = a.wts + sb; c.kept = a.kept + sb; c.first = a.first + sb;
+	c.keep_list = a.keep_list + sb;
+	c.nodes = reinterpret_cast<BtNode*>(a.nodes_) + (sb >> 2) + 4 * (int64_t)r;
+	c.stack = a.stack + 256 * (int64_t)r;
+	c.n_chains = 0; c.n_nodes = 0;
+	a.chain_n[r] = 0; a.kept_seeds[r] = 0;
+	if (a.dbg_chain_n) a.dbg_chain_n[r] = 0;
+	if (S == 0) return;
+
+	// frac_rep: union length of the query spans of over-abundant intervals (bwamem.c:272-279)
+	int l_rep = 0;
+	{
+		const DevIntv *iv = a.intv + (size_t)r * a.cap;
+		int n = a.intv_n[r], b = 0, e = 0;
+		for (int t = 0; t < n; ++t) {
+			if (iv[t].x2 <= (uint64_t)a.opt.max_occ) continue;
+			int sbq = (int)(iv[t].info >> 32), seq = (int)(uint32_t)iv[t].info;
+			if (sbq > e) { l_rep += e - b; b = sbq; e = seq; }
+			else e = e > seq ? e : seq;
+		}
+		l_rep += e - b;
+	}
+	const float frac_rep = (float)l_rep / len;                  // bwamem.c:317
+
+	// greedy chaining (bwamem.c:280-308)
+	c.root = bt_new(c, 0);
+	for (int si = 0; si < S; ++si) {
+		const DevSeed sd = c.seeds[si];
+		if (sd.rid < 0) continue;                               // bwamem.c:294
+		bool to_add = true;
+		if (c.n_chains) {
+			int lower = bt_lower(c, sd.rbeg);
+			if (lower >= 0 && try_merge(c, a.opt, a.ix.l_pac, lower, si)) to_add = false;
+		}
+		if (to_add) {
+			ChainW *ch = &c.cw[c.n_chains];
+			ch->pos = sd.rbeg; ch->head = ch->tail = si; ch->n = 1; ch->rid = sd.rid;
+			c.nxt[si] = -1;
+			bt_put(c, c.n_chains++);
+		}
+	}
+	int n_chn = bt_inorder(c, c.ord);                           // bwamem.c:311-315
+	if (a.dbg_chain_n) {                                        // stage dump: chains before filtering
+		a.dbg_chain_n[r] = n_chn;
+		write_chains(c, a.ix, n_chn, c.ord, frac_rep, false, a.dbg_chains + sb, a.dbg_seeds + sb);
+	}
+
+	// ---- mem_chain_flt (bwamem.c:334-392)
+	if (n_chn == 0) return;
+	int k = 0;
+	for (int i = 0; i < n_chn; ++i) {
+		int ci = c.ord[i];
+		c.first[ci] = -1; c.kept[ci] = 0;
+		c.wts[ci] = chain_weight(c, ci);
+		if (c.wts[ci] >= a.opt.min_chain_weight) c.ord[k++] = ci;
+	}
+	n_chn = k;
+	if (n_chn == 0) return;
+	isort_weight(c, n_chn, c.ord);
+	// NB: `first` and the kept list hold positions in the sorted array, as in the reference
+	int n_keep = 0;
+	c.kept[c.ord[0]] = 3;
+	c.keep_list[n_keep++] = 0;
+	for (int i = 1; i < n_chn; ++i) {
+		const int ai = c.ord[i];
+		int large_ovlp = 0, kk;
+		for (kk = 0; kk < n_keep; ++kk) {
+			const int j = c.keep_list[kk], aj = c.ord[j];
+			int bi = chn_beg(c, ai), bj = chn_beg(c, aj), ei = chn_end(c, ai), ej = chn_end(c, aj);
+			int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+			bool j_alt = a.ix.anns[c.cw[aj].rid].is_alt != 0, i_alt = a.ix.anns[c.cw[ai].rid].is_alt != 0;
+			if (e_min > b_max && (!j_alt || i_alt)) {
+				int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
+				if ((float)(e_min - b_max) >= (float)min_l * a.opt.mask_level && min_l < a.opt.max_chain_gap) {
+					large_ovlp = 1;
+					if (c.first[aj] < 0) c.first[aj] = i;
+					if ((float)c.wts[ai] < (float)c.wts[aj] * a.opt.drop_ratio && c.wts[aj] - c.wts[ai] >= a.opt.min_seed_len << 1) break;
+				}
+			}
+		}
+		if (kk == n_keep) { c.keep_list[n_keep++] = i; c.kept[ai] = large_ovlp ? 2 : 3; }
+	}
+	for (int i = 0; i < n_keep; ++i) {
+		int ci = c.ord[c.keep_list[i]];
+		if (c.first[ci] >= 0) c.kept[c.ord[c.first[ci]]] = 1;
+	}
+	{
+		int i;
+		for (i = k = 0; i < n_chn; ++i) {                       // bwamem.c:380-385
+			int kp = c.kept[c.ord[i]];
+			if (kp == 0 || kp == 3) continue;
+			if (++k >= a.opt.max_chain_extend) break;
+		}
+		for (; i < n_chn; ++i) if (c.kept[c.ord[i]] < 3) c.kept[c.ord[i]] = 0;
+	}
+	int n_out = 0, tot = 0;
+	for (int i = 0; i < n_chn; ++i) {
+		int ci = c.ord[i];
+		if (c.kept[ci] != 0) { c.ord[n_out++] = ci; tot += c.cw[ci].n; }
+	}
+	write_chains(c, a.ix, n_out, c.ord, frac_rep, true, a.chains + sb, a.chain_seeds + sb);
+	a.chain_n[r] = n_out;
+	a.kept_seeds[r] = tot;
+}
+
+} // namespace
+
+int launch_chain(const ChainLaunch &a, hipStream_t st)
+{
+	if (a.n_reads <= 0) return 0;
+	hipLaunchKernelGGL(k_chain, dim3((a.n_reads + 63) / 64), dim3(64), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}

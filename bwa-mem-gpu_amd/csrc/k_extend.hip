@@ -1,0 +1,655 @@
+// K4/K5 -- seed extension and region clean-up: mem_chain2aln (bwamem.c:639-793) with ksw_extend2
+// (ksw.c:380-479), then mem_sort_dedup_patch (bwamem.c:444-496) with mem_patch_reg (bwamem.c:413) and
+// the score-only banded global alignment it needs (bwa_gen_cigar2 bwa.c:261-307, ksw_global2
+// ksw.c:504-584).  One read per wavefront (workgroup = 1 wave, 64 lanes).
+//
+// DP on a wavefront.  Both DPs feed E and F from M (= H(i-1,j-1)+s), not from H (ksw.c:439-447,
+// 556-564), so a row has no serial dependency except F, and F is a max-plus prefix scan:
+//     F(i,j) = max_{k<j} ( max(M_k - oe_ins, 0) + k*e_ins ) - (j-1)*e_ins .
+// Each lane owns CPL adjacent query columns in registers (H and E rows never touch memory); one row
+// = local work + one wavefront exclusive max-scan + three wavefront reductions (row max with last
+// column, first / last non-zero cell for the band trimming of ksw.c:466-469).  Rows stay sequential,
+// which keeps band trimming, z-drop (ksw.c:458-464) and every tie rule exactly as in the reference.
+// Integer DP, no dense contraction: MFMA is not applicable.
+//
+// The per-seed control flow (containment skip bwamem.c:678-713, band doubling bwamem.c:730-741,
+// clip-vs-to-end choice bwamem.c:743-749) is scalar and uniform across the wavefront; tests over
+// lists (previous regions, overlapping seeds) use one lane per element and a ballot.
+#include "bwahip_internal.h"
+
+namespace {
+
+constexpr int NEG = -0x40000000;                             // MINUS_INF of ksw.c:489
+constexpr int MAXQ = BWAHIP_MAX_READ_LEN;                    // query / columns
+constexpr int MAXT = BWAHIP_MAX_READ_LEN + 2 * 200 + 1024;   // reference window: l_query + 2*max_gap(<= 2w) + diagonal drift of the chain
+constexpr int LOW = -0x60000000;                             // below every real DP value, and LOW - 1000*e stays above INT_MIN
+
+__device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wmax(int v) { for (int d = 32; d; d >>= 1) { int o = __shfl_xor(v, d); v = v > o ? v : o; } return v; }
+__device__ __forceinline__ int wmin(int v) { for (int d = 32; d; d >>= 1) { int o = __shfl_xor(v, d); v = v < o ? v : o; } return v; }
+__device__ __forceinline__ int wsum(int v) { for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d); return v; }
+__device__ __forceinline__ int64_t wmax64(int64_t v) { for (int d = 32; d; d >>= 1) { int64_t o = __shfl_xor(v, d); v = v > o ? v : o; } return v; }
+__device__ __forceinline__ int64_t wmin64(int64_t v) { for (int d = 32; d; d >>= 1) { int64_t o = __shfl_xor(v, d); v = v < o ? v : o; } return v; }
+// exclusive prefix max over lanes (lane 0 gets `ident`)
+__device__ __forceinline__ int wscan_excl_max(int v, int ident)
+{
+	const int l = lane();
+	for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (l >= d) v = v > o ? v : o; }
+	int p = __shfl_up(v, 1);
+	return l == 0 ? ident : p;
+}
+
+struct Sw { const int8_t *mat; int o_del, e_del, o_ins, e_ins; };
+
+// ---------------------------------------------------------------------------------------------------
+// ksw_extend2 (ksw.c:380).  q/t live in LDS and are read with a stride (+1 / -1) so the left extension
+// can run on the reversed sequences (bwamem.c:725-729) without copying.  Collective over the wavefront.
+// ---------------------------------------------------------------------------------------------------
+template <int CPL>
+__device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
+                           int w, int end_bonus, int zdrop, int h0, int &qle, int &tle, int &gtle, int &gscore_, int &max_off_,
+                           unsigned long long &cells)
+{
+	const int l = lane(), j0 = l * CPL;
+	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
+	int qv[CPL], Hs[CPL], E[CPL];
+	// first row (ksw.c:396-397) and the query codes of this lane's columns
+	const int h1st = h0 > oe_ins ? h0 - oe_ins : 0;
+#pragma unroll
+	for (int c = 0; c < CPL; ++c) {
+		const int j = j0 + c;
+		qv[c] = j < qlen ? q[j * qs] : 4;
+		int v = 0;
+		if (j == 0) v = h0;
+		else if (j == 1) v = h1st;
+		else if (j <= qlen && h1st - (j - 2) * e_ins > e_ins) v = h1st - (j - 1) * e_ins;
+		Hs[c] = v; E[c] = 0;
+	}
+	// clamp the band (ksw.c:399-407)
+	int mx = 0;
+	for (int i = 0; i < 25; ++i) mx = mx > sw.mat[i] ? mx : sw.mat[i];
+	int max_ins = (int)((double)(qlen * mx + end_bonus - sw.o_ins) / e_ins + 1.);
+	max_ins = max_ins > 1 ? max_ins : 1;
+	w = w < max_ins ? w : max_ins;
+	int max_del = (int)((double)(qlen * mx + end_bonus - sw.o_del) / e_del + 1.);
+	max_del = max_del > 1 ? max_del : 1;
+	w = w < max_del ? w : max_del;
+	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
+	int beg = 0, end = qlen;
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = t[i * ts];
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1 = 0;
+		if (beg == 0) { h1 = h0 - (sw.o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+		cells += (end > beg && l == 0) ? (unsigned long long)(end - beg) : 0ull;
+		int M[CPL], u[CPL], P = NEG;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			const int sc = sw.mat[tb * 5 + qv[c]];
+			M[c] = Hs[c] ? Hs[c] + sc : 0;                         // ksw.c:433
+			int tI = M[c] - oe_ins; tI = tI > 0 ? tI : 0;
+			u[c] = inb ? tI + j * e_ins : NEG;
+			P = P > u[c] ? P : u[c];
+		}
+		int run = wscan_excl_max(P, NEG);
+		int h[CPL], key = -1, firstnz = 1 << 30, lastnz = -1;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			const int f = j == beg ? 0 : run - (j - 1) * e_ins;   // F(i,j); for in-band j > beg `run` holds a real value
+			int hv = M[c] > E[c] ? M[c] : E[c];
+			hv = hv > f ? hv : f;
+			h[c] = inb ? hv : 0;
+			if (inb) {
+				int tD = M[c] - oe_del; tD = tD > 0 ? tD : 0;
+				int en = E[c] - e_del; en = en > tD ? en : tD;
+				E[c] = en;
+				const int k = hv * 1024 + j;                      // row max, last column wins ties (ksw.c:437-438)
+				key = key > k ? key : k;
+			}
+			run = run > u[c] ? run : u[c];
+		}
+		// shift: eh[j+1].h = H(i,j) (ksw.c:432 p->h = h1), eh[beg].h = first-column value, eh[end] = {h1, 0}
+		const int up = __shfl_up(h[CPL - 1], 1);
+#pragma unroll
+		for (int c = CPL - 1; c >= 0; --c) {
+			const int j = j0 + c;
+			const int left = c == 0 ? up : h[c - 1];
+			if (j == beg) Hs[c] = h1;
+			else if (j > beg && j <= end) Hs[c] = left;
+			if (j == end) E[c] = 0;
+			if (j >= beg && j <= end && (Hs[c] != 0 || E[c] != 0)) { firstnz = firstnz < j ? firstnz : j; lastnz = lastnz > j ? lastnz : j; }
+		}
+		key = wmax(key);
+		const int m = key < 0 ? 0 : key >> 10, mj = key < 0 ? -1 : key & 1023;
+		if (end == qlen) {                                        // ksw.c:450-453 (j == qlen after the loop)
+			int hend = 0;
+#pragma unroll
+			for (int c = 0; c < CPL; ++c) if (j0 + c == end) hend = Hs[c];   // eh[end].h = H(i, qlen-1)
+			hend = wmax(hend);
+			if (end == beg) hend = h1;
+			best_ie = gscore > hend ? best_ie : i;
+			gscore = gscore > hend ? gscore : hend;
+		}
+		if (m == 0) break;
+		if (m > best) {
+			best = m; best_i = i; best_j = mj;
+			const int off = mj > i ? mj - i : i - mj;
+			max_off = max_off > off ? max_off : off;
+		} else if (zdrop > 0) {
+			if (i - best_i > mj - best_j) {
+				if (best - m - ((i - best_i) - (mj - best_j)) * e_del > zdrop) break;
+			} else {
+				if (best - m - ((mj - best_j) - (i - best_i)) * e_ins > zdrop) break;
+			}
+		}
+		// band trimming (ksw.c:466-469); `end` itself is a candidate for the backward scan
+		int fz = wmin(firstnz < end ? firstnz : end);            // first non-zero in [beg,end), else end
+		int lz = wmax(lastnz);                                    // last non-zero in [beg,end], else -1
+		const int nbeg = fz;
+		if (lz < nbeg) lz = nbeg - 1;
+		beg = nbeg;
+		end = lz + 2 < qlen ? lz + 2 : qlen;
+	}
+	qle = best_j + 1; tle = best_i + 1; gtle = best_ie + 1; gscore_ = gscore; max_off_ = max_off;
+	return best;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ksw_global2 score only (ksw.c:504-584 without the backtrack matrix).  Same column layout.
+// ---------------------------------------------------------------------------------------------------
+template <int CPL>
+__device__ int wave_global_score(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w,
+                                 unsigned long long &cells)
+{
+	const int l = lane(), j0 = l * CPL;
+	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
+	int qv[CPL], Hs[CPL], E[CPL];
+#pragma unroll
+	for (int c = 0; c < CPL; ++c) {
+		const int j = j0 + c;
+		qv[c] = j < qlen ? q[j * qs] : 4;
+		Hs[c] = j == 0 ? 0 : (j <= qlen && j <= w) ? -(sw.o_ins + e_ins * j) : NEG;   // ksw.c:523-526
+		E[c] = NEG;
+	}
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = t[i * ts];
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const int h1 = beg == 0 ? -(sw.o_del + e_del * (i + 1)) : NEG;
+		cells += (end > beg && l == 0) ? (unsigned long long)(end - beg) : 0ull;
+		int M[CPL], u[CPL], P = LOW;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			M[c] = Hs[c] + sw.mat[tb * 5 + qv[c]];
+			u[c] = inb ? M[c] - oe_ins + j * e_ins : LOW;
+			P = P > u[c] ? P : u[c];
+		}
+		// F(i,beg) = MINUS_INF, F(i,j+1) = max(F(i,j) - e_ins, M_j - oe_ins): fold the initial value in as a
+		// virtual column beg-1 carrying MINUS_INF + e_ins
+		int run = wscan_excl_max(P, LOW);
+		int h[CPL];
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			// F(i,j) = max( F_init - (j-beg)*e_ins , max_{beg<=k<j} u_k - (j-1)*e_ins ),  F_init = MINUS_INF
+			int f = NEG - (j - beg) * e_ins;
+			const int g = run - (j - 1) * e_ins;
+			if (j > beg && run > LOW) f = f > g ? f : g;
+			int hv = M[c] >= E[c] ? M[c] : E[c];
+			hv = hv >= f ? hv : f;
+			h[c] = hv;
+			if (inb) {
+				const int tD = M[c] - oe_del;
+				int en = E[c] - e_del; en = en > tD ? en : tD;
+				E[c] = en;
+			}
+			run = run > u[c] ? run : u[c];
+		}
+		const int up = __shfl_up(h[CPL - 1], 1);
+#pragma unroll
+		for (int c = CPL - 1; c >= 0; --c) {
+			const int j = j0 + c;
+			const int left = c == 0 ? up : h[c - 1];
+			if (j == beg) Hs[c] = h1;
+			else if (j > beg && j <= end) Hs[c] = left;
+			if (j == end) E[c] = NEG;                             // ksw.c:582
+		}
+		if (end == beg) {                                         // empty band: eh[end].h = h1 (only when qlen == 0; kept for fidelity)
+#pragma unroll
+			for (int c = 0; c < CPL; ++c) if (j0 + c == end) Hs[c] = h1;
+		}
+	}
+	int score = LOW;
+#pragma unroll
+	for (int c = 0; c < CPL; ++c) if (j0 + c == qlen) score = Hs[c];
+	return wmax(score);
+}
+
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dev_pos2rid(const DevIndex &ix, int64_t pos_f)   // bntseq.c:354
+{
+	if (pos_f >= ix.l_pac) return -1;
+	int left = 0, mid = 0, right = ix.n_seqs;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= ix.anns[mid].offset) {
+			if (mid == ix.n_seqs - 1) break;
+			if (pos_f < ix.anns[mid + 1].offset) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
+__device__ __forceinline__ int pac_at(const uint8_t *pac, int64_t l) { return pac[l >> 2] >> ((~l & 3) << 1) & 3; }
+// base at coordinate p of the forward+reverse-complement reference (bns_get_seq, bntseq.c:403-424)
+__device__ __forceinline__ int ref_base(const DevIndex &ix, int64_t p)
+{
+	return p < ix.l_pac ? pac_at(ix.pac, p) : 3 - pac_at(ix.pac, (ix.l_pac << 1) - 1 - p);
+}
+__device__ __forceinline__ int cal_max_gap(const DevOpt &o, int qlen)           // bwamem.c:628
+{
+	int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+	int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < o.w << 1 ? l : o.w << 1;
+}
+
+// ---- comparators of bwamem.c:398-402 on an index array into the read's DevReg list; exact introsort ----
+struct RegSort { const DevReg *a; int mode; };                  // mode 0: by re (mem_ars2); 1: score desc, rb, qb (mem_ars)
+__device__ __forceinline__ bool reg_lt(const RegSort s, int x, int y)
+{
+	const DevReg &p = s.a[x], &q = s.a[y];
+	if (s.mode == 0) return p.re < q.re;
+	return p.score > q.score || (p.score == q.score && (p.rb < q.rb || (p.rb == q.rb && p.qb < q.qb)));
+}
+__device__ __forceinline__ void rs_insertion(const RegSort c, int *s, int *t)
+{
+	for (int *i = s + 1; i < t; ++i)
+		for (int *j = i; j > s && reg_lt(c, *j, *(j - 1)); --j) { int tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+__device__ __forceinline__ void rs_comb(const RegSort c, int n, int *a)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	int swapped, gap = n;
+	do {
+		if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		swapped = 0;
+		for (int *i = a; i < a + n - gap; ++i) {
+			int *j = i + gap;
+			if (reg_lt(c, *j, *i)) { int tmp = *i; *i = *j; *j = tmp; swapped = 1; }
+		}
+	} while (swapped || gap > 2);
+	if (gap != 1) rs_insertion(c, a, a + n);
+}
+// `budget` bounds the work so that a logic error can never hang the GPU: on exhaustion the sort stops and
+// the kernel reports BWAHIP_EINTERNAL (never expected; n log n comparisons suffice)
+__device__ __forceinline__ void rs_introsort(const RegSort c, int n, int *a, int *stk, int *bad)   // ksort.h:176-227
+{
+	int d, top = 0, *s, *t, *i, *j, *k, pivot, tmp;
+	long budget = 64L * n * 32 + 1024;
+	if (n < 1) return;
+	if (n == 2) { if (reg_lt(c, a[1], a[0])) { tmp = a[0]; a[0] = a[1]; a[1] = tmp; } return; }
+	for (d = 2; 1 << d < n; ++d);
+	s = a; t = a + (n - 1); d <<= 1;
+	for (;;) {
+		if (--budget < 0) { *bad = 1; return; }
+		if (s < t) {
+			if (--d == 0) { rs_comb(c, (int)(t - s) + 1, s); t = s; continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (reg_lt(c, *k, *i)) { if (reg_lt(c, *k, *j)) k = j; }
+			else k = reg_lt(c, *j, *i) ? i : j;
+			pivot = *k;
+			if (k != t) { tmp = *k; *k = *t; *t = tmp; }
+			for (;;) {
+				do ++i; while (i < t && reg_lt(c, *i, pivot));       // i stops at the pivot (at t) at the latest
+				do --j; while (i <= j && reg_lt(c, pivot, *j));
+				if (j <= i) break;
+				if (--budget < 0) { *bad = 2; return; }
+				tmp = *i; *i = *j; *j = tmp;
+			}
+			tmp = *i; *i = *t; *t = tmp;
+			if (i - s > t - i) {
+				if (i - s > 16) { stk[3*top] = (int)(s - a); stk[3*top+1] = (int)(i - 1 - a); stk[3*top+2] = d; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { stk[3*top] = (int)(i + 1 - a); stk[3*top+1] = (int)(t - a); stk[3*top+2] = d; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) { rs_insertion(c, a, a + n); return; }
+			--top; s = a + stk[3*top]; t = a + stk[3*top+1]; d = stk[3*top+2];
+		}
+	}
+}
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
+{
+	__shared__ uint8_t s_q[MAXQ + 8];
+	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ int8_t s_mat[32];
+	__shared__ int s_stk[3 * 80];
+	const int r = blockIdx.x, l = lane();
+	const DevOpt &opt = a.opt;
+	const DevIndex &ix = a.ix;
+	const int l_query = (int)(a.off[r + 1] - a.off[r]);
+	const uint8_t *query = a.seq + a.off[r];
+	const int64_t sb = a.seed_base[r], rb0 = a.reg_base[r];
+	const int n_chains = a.chain_n[r];
+	const int64_t l_pac = ix.l_pac;
+	DevReg *av = a.regs + rb0;                                  // the read's region list (av of bwamem.c:639)
+	int *srt = a.srt + 2 * sb;                                  // [0..n): seed index in ascending (score,idx) order; [n..2n): skipped flag
+	int n_av = 0;
+	unsigned long long cells = 0;
+	Sw sw; sw.mat = s_mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins;
+	if (l < 25) s_mat[l] = opt.mat[l];
+	for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
+	__syncthreads();
+
+	for (int ci = 0; ci < n_chains; ++ci) {
+		const DevChain ch = a.chains[sb + ci];
+		const DevSeed *seeds = a.chain_seeds + sb + ch.seed_off;
+		const int n = ch.n;
+		if (n == 0) continue;
+		// ---- widest window any seed could reach (bwamem.c:649-664)
+		int64_t rmax0 = l_pac << 1, rmax1 = 0;
+		for (int i = l; i < n; i += 64) {
+			const DevSeed t = seeds[i];
+			int64_t b = t.rbeg - (t.qbeg + cal_max_gap(opt, t.qbeg));
+			int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(opt, l_query - t.qbeg - t.len));
+			rmax0 = rmax0 < b ? rmax0 : b;
+			rmax1 = rmax1 > e ? rmax1 : e;
+		}
+		rmax0 = wmin64(rmax0); rmax1 = wmax64(rmax1);
+		rmax0 = rmax0 > 0 ? rmax0 : 0;
+		rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+		const int64_t seed0_rbeg = seeds[0].rbeg;
+		if (rmax0 < l_pac && l_pac < rmax1) {
+			if (seed0_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+		}
+		// ---- bns_fetch_seq (bntseq.c:426): clamp to the contig of the first seed, load the window into LDS
+		{
+			const bool is_rev = seed0_rbeg >= l_pac;
+			const int rid = dev_pos2rid(ix, is_rev ? (l_pac << 1) - 1 - seed0_rbeg : seed0_rbeg);
+			int64_t far_beg = ix.anns[rid].offset, far_end = far_beg + ix.anns[rid].len;
+			if (is_rev) { int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+			rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+			rmax1 = rmax1 < far_end ? rmax1 : far_end;
+		}
+		const int tl_all = (int)(rmax1 - rmax0);
+		if (tl_all > MAXT) { if (l == 0) atomicExch(a.err, 3); break; }
+		__syncthreads();
+		for (int i = l; i < tl_all; i += 64) s_t[i] = (uint8_t)ref_base(ix, rmax0 + i);
+		// ---- seeds in ascending (score<<32|index) order (bwamem.c:669-672; keys are unique, any sort does)
+		for (int i = l; i < n; i += 64) {
+			const int sc = seeds[i].score;
+			int rank = 0;
+			for (int u = 0; u < n; ++u) { const int su = seeds[u].score; rank += su < sc || (su == sc && u < i); }
+			srt[rank] = i; srt[n + i] = 0;
+		}
+		__threadfence_block();
+		__syncthreads();
+
+		for (int k = n - 1; k >= 0; --k) {                      // best seed first (bwamem.c:674)
+			const int sidx = srt[k];
+			const DevSeed s = seeds[sidx];
+			// ---- is the seed already covered by an earlier region? (bwamem.c:678-694)
+			int hit = -1;
+			for (int base = 0; base < n_av && hit < 0; base += 64) {
+				const int i = base + l;
+				bool brk = false;
+				if (i < n_av) {
+					const DevReg p = av[i];
+					if (!(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) &&
+					    !(s.len - p.seedlen0 > .1 * l_query)) {
+						int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
+						int max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+						int w = max_gap < p.w ? max_gap : p.w;
+						if (qd - rd < w && rd - qd < w) brk = true;
+						else {
+							qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+							max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+							w = max_gap < p.w ? max_gap : p.w;
+							if (qd - rd < w && rd - qd < w) brk = true;
+						}
+					}
+				}
+				const unsigned long long m = __ballot(brk);
+				if (m) hit = base + __ffsll((long long)m) - 1;
+			}
+			if (hit >= 0) {                                     // bwamem.c:696-713: an overlapping, not-colinear better seed?
+				bool any = false;
+				for (int base = k + 1; base < n && !any; base += 64) {
+					const int i = base + l;
+					bool brk = false;
+					if (i < n) {
+						const int ti = srt[i];
+						if (!srt[n + ti]) {                     // srt[i] != 0 (bwamem.c:701)
+							const DevSeed t = seeds[ti];
+							if (!(t.len < s.len * .95)) {
+								if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) brk = true;
+								if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) brk = true;
+							}
+						}
+					}
+					any = __ballot(brk) != 0;
+				}
+				if (!any) { if (l == 0) srt[n + sidx] = 1; __threadfence_block(); __syncthreads(); continue; }
+			}
+			// ---- extend (bwamem.c:716-793)
+			DevReg reg;
+			reg.rb = reg.re = 0; reg.frac_rep = 0; reg.qb = reg.qe = 0; reg.sub = reg.csub = reg.sub_n = 0; reg.seedcov = 0;
+			reg.n_comp = 0; reg.is_alt = 0; reg.pad = 0;
+			reg.rid = ch.rid; reg.score = reg.truesc = -1;
+			int aw0 = opt.w, aw1 = opt.w;
+			if (s.qbeg) {                                       // left extension on the reversed prefixes
+				int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
+				const int tlen = (int)(s.rbeg - rmax0);
+				for (int i = 0; i < 2; ++i) {                   // MAX_BAND_TRY
+					const int prev = reg.score;
+					aw0 = opt.w << i;
+					reg.score = wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
+					                       s.len * opt.a, qle, tle, gtle, gscore, max_off, cells);
+					if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+				}
+				if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
+				else { reg.qb = 0; reg.rb = s.rbeg - gtle; reg.truesc = gscore; }
+			} else { reg.score = reg.truesc = s.len * opt.a; reg.qb = 0; reg.rb = s.rbeg; }
+			if (s.qbeg + s.len != l_query) {                    // right extension
+				int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
+				const int sc0 = reg.score, qe = s.qbeg + s.len, re = (int)(s.rbeg + s.len - rmax0);
+				for (int i = 0; i < 2; ++i) {
+					const int prev = reg.score;
+					aw1 = opt.w << i;
+					reg.score = wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
+					                       qle, tle, gtle, gscore, max_off, cells);
+					if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+				}
+				if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
+				else { reg.qe = l_query; reg.re = rmax0 + re + gtle; reg.truesc += gscore - sc0; }
+			} else { reg.qe = l_query; reg.re = s.rbeg + s.len; }
+			int cov = 0;                                        // seedcov (bwamem.c:782-786)
+			for (int i = l; i < n; i += 64) {
+				const DevSeed t = seeds[i];
+				if (t.qbeg >= reg.qb && t.qbeg + t.len <= reg.qe && t.rbeg >= reg.rb && t.rbeg + t.len <= reg.re) cov += t.len;
+			}
+			reg.seedcov = wsum(cov);
+			reg.w = aw0 > aw1 ? aw0 : aw1;
+			reg.seedlen0 = s.len;
+			reg.frac_rep = ch.frac_rep;
+			if (l == 0) av[n_av] = reg;
+			++n_av;
+			__threadfence_block();
+			__syncthreads();
+		}
+	}
+	if (a.dbg_regs) {                                           // stage dump: regions before mem_sort_dedup_patch
+		for (int i = l; i < n_av; i += 64) a.dbg_regs[rb0 + i] = av[i];
+		if (l == 0) a.dbg_reg_n[r] = n_av;
+	}
+
+	// ---- mem_sort_dedup_patch (bwamem.c:444-496) + is_alt (bwamem.c:1091-1095).  The scalar logic is replicated
+	// in every lane (identical reads of av[]), stores are done by lane 0; the rare banded global alignment is
+	// collective.  The sort permutes an index array; the list is then gathered into that order.
+	int n = n_av;
+	if (n > 1) {
+		int *idx = srt;                                         // reuse: needs n ints (n <= number of seeds)
+		// sort by re
+		if (l == 0) { for (int i = 0; i < n; ++i) idx[i] = i; int bad = 0; rs_introsort(RegSort{av, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
+		__threadfence_block(); __syncthreads();
+		// gather into sorted order through the spare list (all lanes), then copy back
+		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
+		__threadfence_block(); __syncthreads();
+		for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+		__threadfence_block(); __syncthreads();
+		if (l == 0) for (int i = 0; i < n; ++i) av[i].n_comp = 1;
+		__threadfence_block(); __syncthreads();
+		for (int i = 1; i < n; ++i) {
+			DevReg p = av[i];
+			const DevReg pm = av[i - 1];
+			if (p.rid != pm.rid || p.rb >= pm.re + opt.max_chain_gap) continue;
+			bool p_dirty = false;
+			for (int j = i - 1; j >= 0; --j) {
+				DevReg q = av[j];
+				if (!(p.rid == q.rid && p.rb < q.re + opt.max_chain_gap)) break;
+				if (q.qe == q.qb) continue;                     // excluded
+				const int64_t orr = q.re - p.rb;
+				const int64_t oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+				const int64_t mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+				const int64_t mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+				if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
+					if (p.score < q.score) { p.qe = p.qb; p_dirty = true; break; }
+					else { q.qe = q.qb; if (l == 0) av[j].qe = q.qe; __threadfence_block(); __syncthreads(); }
+				} else if (q.rb < p.rb) {
+					// ---- mem_patch_reg (bwamem.c:413-442), a = q, b = p
+					int score = 0, wband = 0;
+					bool ok = true;
+					if (q.rb < l_pac && p.rb >= l_pac) ok = false;
+					if (ok && (q.qb >= p.qb || q.qe >= p.qe || q.re >= p.re)) ok = false;
+					if (ok) {
+						int w = (int)((q.re - p.rb) - (q.qe - p.qb));
+						w = w > 0 ? w : -w;
+						double rr = (double)(q.re - p.rb) / (p.re - q.rb) - (double)(q.qe - p.qb) / (p.qe - q.qb);
+						rr = rr > 0. ? rr : -rr;
+						if (q.re < p.rb || q.qe < p.qb) { if (w > opt.w << 1 || rr >= 0.05f) ok = false; }
+						else if (w > opt.w << 2 || rr >= 0.05f * 2) ok = false;
+						if (ok) {
+							w += q.w + p.w;
+							w = w < opt.w << 2 ? w : opt.w << 2;
+							// bwa_gen_cigar2 score only (bwa.c:261-307): query[q.qb, p.qe) vs ref [q.rb, p.re)
+							const int lq = p.qe - q.qb;
+							const int64_t grb = q.rb, gre = p.re;
+							int gsc = 0;
+							bool have = !(lq <= 0 || grb >= gre || (grb < l_pac && gre > l_pac));
+							const int rlen = (int)(gre - grb);
+							if (have && rlen > MAXT) { if (l == 0) atomicExch(a.err, 4); have = false; }
+							if (have) {
+								__syncthreads();
+								for (int t = l; t < rlen; t += 64) s_t[t] = (uint8_t)ref_base(ix, grb + t);
+								__syncthreads();
+								const bool rev = grb >= l_pac;      // both reversed so gaps are left-aligned on the forward strand (bwa.c:275-280)
+								if (lq == rlen && w == 0) {
+									int part = 0;
+									for (int t = l; t < lq; t += 64) part += s_mat[s_t[t] * 5 + s_q[q.qb + t]];
+									gsc = wsum(part);
+								} else {
+									int max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+									int max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+									int max_gap = max_ins > max_del ? max_ins : max_del;
+									max_gap = max_gap > 1 ? max_gap : 1;
+									int dl = rlen - lq; dl = dl < 0 ? -dl : dl;
+									int gw = (max_gap + dl + 1) >> 1;
+									gw = gw < w ? gw : w;
+									const int min_w = dl + 3;
+									gw = gw > min_w ? gw : min_w;
+									gsc = rev ? wave_global_score<CPL>(sw, s_q + p.qe - 1, -1, lq, s_t + rlen - 1, -1, rlen, gw, cells)
+									          : wave_global_score<CPL>(sw, s_q + q.qb, 1, lq, s_t, 1, rlen, gw, cells);
+								}
+								score = gsc;
+								const int q_s = (int)((double)(p.qe - q.qb) / ((p.qe - p.qb) + (q.qe - q.qb)) * (p.score + q.score) + .499);
+								const int r_s = (int)((double)(p.re - q.rb) / ((p.re - p.rb) + (q.re - q.rb)) * (p.score + q.score) + .499);
+								if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) score = 0;
+								wband = w;
+							} else score = 0;                   // bwa_gen_cigar2 returned without a score: the reference reads an
+							                                     // uninitialised int here; unreachable for regions of one chain strand
+						} else score = 0;
+					}
+					if (ok && score > 0) {                      // merge q into p (bwamem.c:470-478)
+						p.n_comp += q.n_comp + 1;
+						p.seedcov = p.seedcov > q.seedcov ? p.seedcov : q.seedcov;
+						p.sub = p.sub > q.sub ? p.sub : q.sub;
+						p.csub = p.csub > q.csub ? p.csub : q.csub;
+						p.qb = q.qb; p.rb = q.rb;
+						p.truesc = p.score = score;
+						p.w = wband;
+						q.qb = q.qe;
+						p_dirty = true;
+						if (l == 0) av[j].qb = q.qb;
+						__threadfence_block(); __syncthreads();
+					}
+				}
+			}
+			if (p_dirty) {                                      // write back only what a merge / exclusion can change
+				if (l == 0) {
+					DevReg *d = &av[i];
+					d->qe = p.qe; d->qb = p.qb; d->rb = p.rb; d->n_comp = p.n_comp; d->seedcov = p.seedcov;
+					d->sub = p.sub; d->csub = p.csub; d->truesc = p.truesc; d->score = p.score; d->w = p.w;
+				}
+				__threadfence_block(); __syncthreads();
+			}
+		}
+		// compact, sort by (score desc, rb, qb), drop identical hits (bwamem.c:481-495)
+		if (l == 0) {
+			int m = 0;
+			for (int i = 0; i < n; ++i) if (av[i].qe > av[i].qb) { if (m != i) av[m] = av[i]; ++m; }
+			for (int i = 0; i < m; ++i) idx[i] = i;
+			int bad = 0; rs_introsort(RegSort{av, 1}, m, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad);
+			s_stk[0] = m;
+		}
+		__threadfence_block(); __syncthreads();
+		n = s_stk[0];
+		__syncthreads();
+		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
+		__threadfence_block(); __syncthreads();
+		for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+		__threadfence_block(); __syncthreads();
+		if (l == 0) {
+			for (int i = 1; i < n; ++i)
+				if (av[i].score == av[i-1].score && av[i].rb == av[i-1].rb && av[i].qb == av[i-1].qb) av[i].qe = av[i].qb;
+			int m = n > 0 ? 1 : 0;
+			for (int i = 1; i < n; ++i) if (av[i].qe > av[i].qb) { if (m != i) av[m] = av[i]; ++m; }
+			s_stk[0] = m;
+		}
+		__threadfence_block(); __syncthreads();
+		n = s_stk[0];
+		__syncthreads();
+	}
+	for (int i = l; i < n; i += 64) {                           // bwamem.c:1091-1095
+		if (av[i].rid >= 0 && ix.anns[av[i].rid].is_alt) av[i].is_alt = 1;
+	}
+	if (l == 0) {
+		a.reg_n[r] = n;
+		if (cells) atomicAdd(&a.counters[CNT_CELLS], cells);
+	}
+}
+
+} // namespace
+
+int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
+{
+	if (a.n_reads <= 0) return 0;
+	// columns 0..max_len must fit in 64 lanes x CPL registers
+	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend<3>, dim3(a.n_reads), dim3(64), 0, st, a);
+	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend<5>, dim3(a.n_reads), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_extend<11>, dim3(a.n_reads), dim3(64), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, int64_t *out, int 
 }
 } // namespace
 
-static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds" };
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend" };
 
 struct bwahip_ctx {
 	int device = 0;
@@ -59,9 +59,13 @@ struct bwahip_ctx {
 	DevBuf d_seq, d_off;
 	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
 	DevBuf d_misc;                       // [0..15] counters (u64), then queue (u32), err (i32)
+	// K3/K4 working set (sized from the seed count of the batch)
+	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
+	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n;
 	int intv_cap = 96;
-	int64_t total_seeds = 0;
-	hipEvent_t ev[8];
+	int64_t total_seeds = 0, total_regs = 0;
+	hipEvent_t ev[16];
 	float last_ms[8];
 };
 
@@ -185,7 +189,10 @@ void bwahip_destroy(bwahip_ctx *c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
-	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc };
+	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
+	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
+	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -266,8 +273,10 @@ int bwahip_batch_upload(bwahip_ctx *c, int n, const uint8_t *seq, const int64_t 
 int bwahip_n_kernels(void) { return (int)(sizeof(g_kernel_names) / sizeof(g_kernel_names[0])); }
 const char *bwahip_kernel_name(int i) { return i >= 0 && i < bwahip_n_kernels() ? g_kernel_names[i] : ""; }
 
-static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed)
+static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 {
+	const bool verbose = getenv("BWAHIP_VERBOSE") != nullptr;
+#define STAGE_LOG(name) do { if (verbose) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bwahip] %s done (%s)\n", name, hipGetErrorString(hipGetLastError())); fflush(stderr); } } while (0)
 	const int n = c->n_reads;
 	if (n == 0) return 0;
 	DevOpt dopt = make_dev_opt(opt);
@@ -291,6 +300,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed)
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
 		if ((rc = launch_smem(sl, 8, c->stream))) return rc;
+		STAGE_LOG("k_smem");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n);
 		if (timed) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
@@ -315,12 +325,67 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed)
 		se.seed_base = c->d_seed_base.as<int64_t>(); se.seeds = c->d_seeds.as<DevSeed>(); se.counters = counters;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
 		if ((rc = launch_seeds(se, total, c->stream))) return rc;
+		STAGE_LOG("k_seeds");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+		// ---- K3: chaining + chain filter
+		const size_t T = (size_t)(total ? total : 1);
+		if ((rc = c->d_cw.ensure(T * sizeof(ChainWOpaque))) || (rc = c->d_nxt.ensure(T * 4)) || (rc = c->d_ord.ensure(T * 4)) ||
+		    (rc = c->d_wts.ensure(T * 4)) || (rc = c->d_kept.ensure(T * 4)) || (rc = c->d_first.ensure(T * 4)) || (rc = c->d_keep.ensure(T * 4)) ||
+		    (rc = c->d_nodes.ensure(((T >> 2) + 4 * (size_t)n + 8) * sizeof(BtNodeOpaque))) || (rc = c->d_stack.ensure((size_t)n * 256 * 4)) ||
+		    (rc = c->d_chains.ensure(T * sizeof(DevChain))) || (rc = c->d_chain_seeds.ensure(T * sizeof(DevSeed))) ||
+		    (rc = c->d_chain_n.ensure((size_t)n * 4)) || (rc = c->d_kept_seeds.ensure((size_t)n * 4)) || (rc = c->d_reg_base.ensure((size_t)(n + 1) * 8)))
+			return rc;
+		if (dump && ((rc = c->d_dbg_chains.ensure(T * sizeof(DevChain))) || (rc = c->d_dbg_seeds.ensure(T * sizeof(DevSeed))) || (rc = c->d_dbg_chain_n.ensure((size_t)n * 4))))
+			return rc;
+		ChainLaunch cl;
+		memset(&cl, 0, sizeof cl);
+		cl.ix = c->ix; cl.opt = dopt; cl.n_reads = n; cl.off = c->d_off.as<int64_t>();
+		cl.intv = c->d_intv.as<DevIntv>(); cl.intv_n = c->d_intv_n.as<int>(); cl.cap = cap;
+		cl.seed_base = c->d_seed_base.as<int64_t>(); cl.seeds = c->d_seeds.as<DevSeed>();
+		cl.cw_ = c->d_cw.as<ChainWOpaque>(); cl.nxt = c->d_nxt.as<int>(); cl.ord = c->d_ord.as<int>(); cl.wts = c->d_wts.as<int>();
+		cl.kept = c->d_kept.as<int>(); cl.first = c->d_first.as<int>(); cl.keep_list = c->d_keep.as<int>();
+		cl.nodes_ = c->d_nodes.as<BtNodeOpaque>(); cl.stack = c->d_stack.as<int>();
+		cl.chains = c->d_chains.as<DevChain>(); cl.chain_seeds = c->d_chain_seeds.as<DevSeed>();
+		cl.chain_n = c->d_chain_n.as<int>(); cl.kept_seeds = c->d_kept_seeds.as<int>();
+		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }
+		if (timed) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+		if ((rc = launch_chain(cl, c->stream))) return rc;
+		STAGE_LOG("k_chain");
+		if (timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
+		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_kept_seeds.as<int>(), c->d_reg_base.as<int64_t>(), n);
+		if (timed) HIP_TRY(hipEventRecord(c->ev[7], c->stream));
+		int64_t total_regs = 0;
+		HIP_TRY(hipMemcpyAsync(&total_regs, c->d_reg_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->total_regs = total_regs;
+		// ---- K4/K5: extension + sort/dedup/patch
+		const size_t R = (size_t)(total_regs ? total_regs : 1);
+		if ((rc = c->d_regs.ensure(R * sizeof(DevReg))) || (rc = c->d_tmp_regs.ensure(R * sizeof(DevReg))) || (rc = c->d_reg_n.ensure((size_t)n * 4)) ||
+		    (rc = c->d_srt.ensure(T * 8))) return rc;
+		if (dump && ((rc = c->d_dbg_regs.ensure(R * sizeof(DevReg))) || (rc = c->d_dbg_reg_n.ensure((size_t)n * 4)))) return rc;
+		ExtLaunch el;
+		memset(&el, 0, sizeof el);
+		el.ix = c->ix; el.opt = dopt; el.n_reads = n; el.seq = c->d_seq.as<uint8_t>(); el.off = c->d_off.as<int64_t>();
+		el.seed_base = c->d_seed_base.as<int64_t>(); el.chains = c->d_chains.as<DevChain>(); el.chain_seeds = c->d_chain_seeds.as<DevSeed>();
+		el.chain_n = c->d_chain_n.as<int>(); el.reg_base = c->d_reg_base.as<int64_t>();
+		el.regs = c->d_regs.as<DevReg>(); el.reg_n = c->d_reg_n.as<int>(); el.tmp_regs = c->d_tmp_regs.as<DevReg>(); el.srt = c->d_srt.as<int>();
+		if (dump) { el.dbg_regs = c->d_dbg_regs.as<DevReg>(); el.dbg_reg_n = c->d_dbg_reg_n.as<int>(); }
+		el.counters = counters; el.err = err;
+		if (timed) HIP_TRY(hipEventRecord(c->ev[8], c->stream));
+		if (verbose) fprintf(stderr, "[bwahip] seeds=%lld regs_cap=%lld\n", (long long)total, (long long)total_regs);
+		if ((rc = launch_extend(el, c->max_len, c->stream))) return rc;
+		STAGE_LOG("k_extend");
+		if (timed) HIP_TRY(hipEventRecord(c->ev[9], c->stream));
+		HIP_TRY(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (h_err) { fprintf(stderr, "[bwahip] extension kernel reported code %d (reference window or read beyond compiled limits)\n", h_err); return h_err >= 3 ? BWAHIP_ECAPACITY : BWAHIP_EINTERNAL; }
 		if (timed) {
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[6]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[4], c->ev[6], c->ev[7]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[5], c->ev[8], c->ev[9]));
 		}
 		return 0;
 	}
@@ -331,7 +396,7 @@ int bwahip_batch_run(bwahip_ctx *c, const bwahip_opt_t *opt, float *kernel_ms, i
 {
 	if (!c || !opt) return BWAHIP_EINVAL;
 	HIP_TRY(hipSetDevice(c->device));
-	int rc = run_pipeline(c, opt, true);
+	int rc = run_pipeline(c, opt, true, false);
 	if (!rc && kernel_ms) for (int i = 0; i < n_ms && i < bwahip_n_kernels(); ++i) kernel_ms[i] = c->last_ms[i];
 	return rc;
 }
@@ -346,7 +411,33 @@ int bwahip_batch_counters(bwahip_ctx *c, uint64_t *counters, int n)
 	return 0;
 }
 
-int bwahip_batch_download(bwahip_ctx *, bwahip_alnreg_v *) { return BWAHIP_EINVAL; }   // filled in when K4/K5 land
+int bwahip_batch_download(bwahip_ctx *c, bwahip_alnreg_v *out)
+{
+	if (!c || !out) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	const int n = c->n_reads;
+	if (n == 0) return 0;
+	std::vector<int> h_regn(n);
+	std::vector<int64_t> h_rbase(n + 1);
+	std::vector<DevReg> h_regs((size_t)c->total_regs + 1);
+	HIP_TRY(hipMemcpy(h_regn.data(), c->d_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(h_rbase.data(), c->d_reg_base.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+	if (c->total_regs) HIP_TRY(hipMemcpy(h_regs.data(), c->d_regs.p, (size_t)c->total_regs * sizeof(DevReg), hipMemcpyDeviceToHost));
+	for (int i = 0; i < n; ++i) {
+		const int m = h_regn[i];
+		out[i].n = out[i].m = m;
+		out[i].a = m ? (bwahip_alnreg_t*)calloc(m, sizeof(bwahip_alnreg_t)) : nullptr;   // kv_init'ed vector when empty (bwamem.c:1075)
+		if (m && !out[i].a) return BWAHIP_ENOMEM;
+		for (int k = 0; k < m; ++k) {
+			const DevReg &p = h_regs[h_rbase[i] + k];
+			bwahip_alnreg_t &q = out[i].a[k];                  // memset(0) + the fields mem_chain2aln / dedup set
+			q.rb = p.rb; q.re = p.re; q.frac_rep = p.frac_rep; q.qb = p.qb; q.qe = p.qe; q.rid = p.rid; q.score = p.score; q.truesc = p.truesc;
+			q.sub = p.sub; q.csub = p.csub; q.sub_n = p.sub_n; q.w = p.w; q.seedcov = p.seedcov; q.seedlen0 = p.seedlen0;
+			q.n_comp = p.n_comp; q.is_alt = p.is_alt;
+		}
+	}
+	return 0;
+}
 
 // ------------------------------------------------------------------ stage dump (i64 records)
 static void rec(std::vector<int64_t> &o, int64_t tag, const std::vector<int64_t> &v)
@@ -361,7 +452,7 @@ int bwahip_run_stages(bwahip_ctx *c, const bwahip_opt_t *opt, int n, const uint8
 	if (!c || !opt || !out || !out_len) return BWAHIP_EINVAL;
 	int rc = bwahip_batch_upload(c, n, seq, off);
 	if (rc) return rc;
-	if ((rc = run_pipeline(c, opt, false))) return rc;
+	if ((rc = run_pipeline(c, opt, false, true))) return rc;
 	std::vector<int64_t> o;
 	std::vector<int> h_n(n ? n : 1);
 	std::vector<DevIntv> h_iv((size_t)n * c->intv_cap + 1);
@@ -375,6 +466,50 @@ int bwahip_run_stages(bwahip_ctx *c, const bwahip_opt_t *opt, int n, const uint8
 		HIP_TRY(hipMemcpy(h_base.data(), c->d_seed_base.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
 		if (c->total_seeds) HIP_TRY(hipMemcpy(h_seeds.data(), c->d_seeds.p, (size_t)c->total_seeds * sizeof(DevSeed), hipMemcpyDeviceToHost));
 	}
+	auto f2i = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (int64_t)u; };
+	const size_t T = (size_t)c->total_seeds + 1, R = (size_t)c->total_regs + 1;
+	std::vector<DevChain> h_ch(T), h_dch(T);
+	std::vector<DevSeed> h_cs(T), h_dcs(T);
+	std::vector<int> h_chn(n + 1), h_dchn(n + 1), h_regn(n + 1), h_dregn(n + 1);
+	std::vector<int64_t> h_rbase(n + 1, 0);
+	std::vector<DevReg> h_regs(R), h_dregs(R);
+	if (n) {
+		if (c->total_seeds) {
+			HIP_TRY(hipMemcpy(h_ch.data(), c->d_chains.p, (size_t)c->total_seeds * sizeof(DevChain), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_cs.data(), c->d_chain_seeds.p, (size_t)c->total_seeds * sizeof(DevSeed), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_dch.data(), c->d_dbg_chains.p, (size_t)c->total_seeds * sizeof(DevChain), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_dcs.data(), c->d_dbg_seeds.p, (size_t)c->total_seeds * sizeof(DevSeed), hipMemcpyDeviceToHost));
+		}
+		HIP_TRY(hipMemcpy(h_chn.data(), c->d_chain_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_dchn.data(), c->d_dbg_chain_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_regn.data(), c->d_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_dregn.data(), c->d_dbg_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_rbase.data(), c->d_reg_base.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+		if (c->total_regs) {
+			HIP_TRY(hipMemcpy(h_regs.data(), c->d_regs.p, (size_t)c->total_regs * sizeof(DevReg), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_dregs.data(), c->d_dbg_regs.p, (size_t)c->total_regs * sizeof(DevReg), hipMemcpyDeviceToHost));
+		}
+	}
+	auto put_chains = [&](std::vector<int64_t> &v, int cnt, const DevChain *ch, const DevSeed *sd) {
+		v.push_back(cnt);
+		for (int k = 0; k < cnt; ++k) {
+			const DevChain &h = ch[k];
+			v.push_back(h.pos); v.push_back(h.rid); v.push_back(h.is_alt); v.push_back(h.w); v.push_back(h.kept);
+			v.push_back(h.first); v.push_back(f2i(h.frac_rep)); v.push_back(h.n);
+			for (int t = 0; t < h.n; ++t) { const DevSeed &d = sd[h.seed_off + t]; v.push_back(d.rbeg); v.push_back(d.qbeg); v.push_back(d.len); v.push_back(d.score); }
+		}
+	};
+	auto put_regs = [&](std::vector<int64_t> &v, int cnt, const DevReg *rg) {
+		v.push_back(cnt);
+		for (int k = 0; k < cnt; ++k) {
+			const DevReg &p = rg[k];
+			v.push_back(p.rb); v.push_back(p.re); v.push_back(p.qb); v.push_back(p.qe); v.push_back(p.rid);
+			v.push_back(p.score); v.push_back(p.truesc); v.push_back(p.sub); v.push_back(0); v.push_back(p.csub);
+			v.push_back(p.sub_n); v.push_back(p.w); v.push_back(p.seedcov); v.push_back(0);
+			v.push_back(0); v.push_back(p.seedlen0); v.push_back(p.n_comp); v.push_back(p.is_alt);
+			v.push_back(f2i(p.frac_rep));
+		}
+	};
 	for (int i = 0; i < n; ++i) {
 		std::vector<int64_t> v = { (int64_t)i, off[i + 1] - off[i] };
 		rec(o, 100, v);
@@ -393,6 +528,10 @@ int bwahip_run_stages(bwahip_ctx *c, const bwahip_opt_t *opt, int n, const uint8
 			}
 			rec(o, 6, v);
 		}
+		if (stage_mask & (1 << BWAHIP_STAGE_CHAIN)) { v.clear(); put_chains(v, h_dchn[i], &h_dch[h_base[i]], &h_dcs[h_base[i]]); rec(o, BWAHIP_STAGE_CHAIN, v); }
+		if (stage_mask & (1 << BWAHIP_STAGE_CHAIN_FLT)) { v.clear(); put_chains(v, h_chn[i], &h_ch[h_base[i]], &h_cs[h_base[i]]); rec(o, BWAHIP_STAGE_CHAIN_FLT, v); }
+		if (stage_mask & (1 << BWAHIP_STAGE_REGS_PRE)) { v.clear(); put_regs(v, h_dregn[i], &h_dregs[h_rbase[i]]); rec(o, BWAHIP_STAGE_REGS_PRE, v); }
+		if (stage_mask & (1 << BWAHIP_STAGE_REGS)) { v.clear(); put_regs(v, h_regn[i], &h_regs[h_rbase[i]]); rec(o, BWAHIP_STAGE_REGS, v); }
 	}
 	*out_len = (int64_t)o.size();
 	*out = (int64_t*)malloc(o.size() * 8 + 8);
@@ -401,7 +540,32 @@ int bwahip_run_stages(bwahip_ctx *c, const bwahip_opt_t *opt, int n, const uint8
 	return 0;
 }
 
-int bwahip_align_batch(bwahip_ctx *, const bwahip_opt_t *, int, bwahip_seq_t *, bwahip_alnreg_v *) { return BWAHIP_EINVAL; }
+static const uint8_t k_nt4[256] = {      // nst_nt4_table, bntseq.c:46
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,5,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,0,4,1, 4,4,4,2, 4,4,4,4, 4,4,4,4,  4,4,4,4, 3,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,0,4,1, 4,4,4,2, 4,4,4,4, 4,4,4,4,  4,4,4,4, 3,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4
+};
+
+int bwahip_align_batch(bwahip_ctx *c, const bwahip_opt_t *opt, int n, bwahip_seq_t *seqs, bwahip_alnreg_v *regs_out)
+{
+	if (!c || !opt || n < 0 || (n && (!seqs || !regs_out))) return BWAHIP_EINVAL;
+	std::vector<int64_t> off(n + 1, 0);
+	for (int i = 0; i < n; ++i) { if (seqs[i].l_seq < 0) return BWAHIP_EINVAL; off[i + 1] = off[i] + seqs[i].l_seq; }
+	std::vector<uint8_t> codes((size_t)off[n] + 1);
+	for (int i = 0; i < n; ++i) {                         // in-place conversion exactly as bwamem.c:1067-1068
+		char *s = seqs[i].seq;
+		for (int k = 0; k < seqs[i].l_seq; ++k) { s[k] = s[k] < 4 ? s[k] : (char)k_nt4[(uint8_t)s[k]]; codes[off[i] + k] = (uint8_t)s[k]; }
+	}
+	int rc = bwahip_batch_upload(c, n, codes.data(), off.data());
+	if (rc) return rc;
+	if ((rc = run_pipeline(c, opt, false, false))) return rc;
+	return bwahip_batch_download(c, regs_out);
+}
 int bwahip_process_seqs(bwahip_ctx *, const bwahip_opt_t *, int64_t, int, bwahip_seq_t *, const bwahip_pestat_t *) { return BWAHIP_EINVAL; }
 int bwahip_kat_ksw_extend(bwahip_ctx *, int, const int *, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *, int *) { return BWAHIP_EINVAL; }
 

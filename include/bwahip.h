@@ -152,7 +152,9 @@ typedef struct { uint64_t x[3], info; } bwahip_intv_t;              /* bwtintv_t
 #define BWAHIP_ECAPACITY  -5   /* a read exceeds the compiled limits (length > BWAHIP_MAX_READ_LEN) */
 #define BWAHIP_EINTERNAL  -6   /* a kernel reported an inconsistency (never expected) */
 
-#define BWAHIP_MAX_READ_LEN 1000
+/* Longest read the kernels accept.  Below ~730 bp mem_flt_chained_seeds (bwamem.c:605) returns at its first
+ * test (5.5*ln(l) > 0.05*l), so the seed SW filter it would run is provably dormant for every accepted read. */
+#define BWAHIP_MAX_READ_LEN 700
 
 typedef struct bwahip_ctx bwahip_ctx;
 
