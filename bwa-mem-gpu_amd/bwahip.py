@@ -47,6 +47,21 @@ class AlnRegV(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("a", C.POINTER(AlnReg))]
 
 
+class Bwt(C.Structure):  # bwahip_bwt_t == bwt_t (bwt.h:48-60)
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.c_void_p), ("cnt_table", C.c_uint32 * 256), ("sa_intv", C.c_int), ("n_sa", C.c_uint64), ("sa", C.c_void_p)]
+
+
+class Ann(C.Structure):  # bwahip_ann_t == bntann1_t (bntseq.h:41-48)
+    _fields_ = [("offset", C.c_int64), ("len", C.c_int32), ("n_ambs", C.c_int32), ("gi", C.c_uint32), ("is_alt", C.c_int32),
+                ("name", C.c_char_p), ("anno", C.c_char_p)]
+
+
+class Bns(C.Structure):  # bwahip_bns_t == bntseq_t (bntseq.h:56-64)
+    _fields_ = [("l_pac", C.c_int64), ("n_seqs", C.c_int32), ("seed", C.c_uint32), ("anns", C.POINTER(Ann)), ("n_holes", C.c_int32),
+                ("ambs", C.c_void_p), ("fp_pac", C.c_void_p)]
+
+
 class PeStat(C.Structure):
     _fields_ = [("low", C.c_int), ("high", C.c_int), ("failed", C.c_int), ("avg", C.c_double), ("std", C.c_double)]
 
@@ -77,6 +92,7 @@ def lib():
     L.bwahip_version.restype = C.c_char_p
     L.bwahip_opt_init.argtypes = [C.POINTER(Opt)]
     L.bwahip_init_from_files.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
     L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
     L.bwahip_batch_upload.argtypes = [vp, C.c_int, vp, vp]
@@ -140,7 +156,29 @@ class Context:
 
     def __init__(self, prefix, device=0):
         self._h = C.c_void_p()
-        _check(lib().bwahip_init_from_files(os.fsencode(prefix), device, C.byref(self._h)), "bwahip_init_from_files")
+        self._keep = None
+        if prefix is not None:
+            _check(lib().bwahip_init_from_files(os.fsencode(prefix), device, C.byref(self._h)), "bwahip_init_from_files")
+
+    @classmethod
+    def from_device_arrays(cls, meta, bwt_ptr, sa_ptr, pac_ptr, device=0):
+        """Adopt index arrays that already sit in HBM (bwahip_init_device), e.g. after the RCCL broadcast."""
+        self = cls(None, device)
+        b = Bwt()
+        b.primary = meta["primary"]
+        for i in range(5):
+            b.L2[i] = meta["L2"][i]
+        b.seq_len, b.bwt_size, b.bwt = meta["seq_len"], meta["bwt_words"], bwt_ptr
+        b.sa_intv, b.n_sa, b.sa = meta["sa_intv"], meta["n_sa"], sa_ptr
+        anns = (Ann * len(meta["contigs"]))()
+        for i, (name, off, ln, alt) in enumerate(meta["contigs"]):
+            anns[i].offset, anns[i].len, anns[i].is_alt = off, ln, alt
+            anns[i].name, anns[i].anno = name.encode(), b""
+        n = Bns()
+        n.l_pac, n.n_seqs, n.seed, n.anns = meta["l_pac"], len(meta["contigs"]), 11, anns
+        self._keep = (b, anns, n)
+        _check(lib().bwahip_init_device(C.byref(b), C.byref(n), pac_ptr, device, C.byref(self._h)), "bwahip_init_device")
+        return self
 
     def close(self):
         if self._h:
@@ -166,6 +204,29 @@ class Context:
         words = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.int64)
         C.CDLL(None).free(out)
         return parse_records(words)
+
+    def process_seqs(self, names, seqs, quals=None, opt=None, n_processed=0):
+        """mem_process_seqs: list of names / ASCII reads (/ quals) -> list of SAM text (bytes) per read."""
+        opt = opt or default_opt()
+        n = len(seqs)
+        arr = (Seq * n)()
+        keep = []
+        for i in range(n):
+            sb = C.create_string_buffer(bytes(seqs[i]), len(seqs[i]) + 1)
+            keep.append(sb)
+            arr[i].l_seq, arr[i].id = len(seqs[i]), i
+            arr[i].name = bytes(names[i])
+            arr[i].comment = None
+            arr[i].seq = C.cast(sb, C.POINTER(C.c_char))
+            arr[i].qual = bytes(quals[i]) if quals is not None else None
+        _check(lib().bwahip_process_seqs(self._h, C.byref(opt), n_processed, n, arr, None), "bwahip_process_seqs")
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        out = []
+        for i in range(n):
+            out.append(C.string_at(arr[i].sam))
+            libc.free(C.cast(arr[i].sam, C.c_void_p))
+        return out
 
     def batch_upload(self, codes, off):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)

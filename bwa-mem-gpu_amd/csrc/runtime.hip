@@ -48,6 +48,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, int64_t *out, int 
 static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend" };
 
 struct bwahip_ctx {
+	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
 	hipStream_t stream = nullptr;
 	HostIndex host;                      // host copy (owned when loaded from files)
@@ -128,9 +129,13 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
 	int rc;
-	if ((rc = upload(c->d_bwt, bwt->bwt, bwt->bwt_size * 4, c->stream))) return rc;
-	if ((rc = upload(c->d_sa, bwt->sa, bwt->n_sa * 8, c->stream))) return rc;
-	if ((rc = upload(c->d_pac, pac, (size_t)bns->l_pac / 4 + 1, c->stream))) return rc;
+	if (c->external_index) {             // adopt caller-owned device arrays (e.g. received over RCCL)
+		c->d_bwt.p = bwt->bwt; c->d_sa.p = bwt->sa; c->d_pac.p = (void*)pac;
+	} else {
+		if ((rc = upload(c->d_bwt, bwt->bwt, bwt->bwt_size * 4, c->stream))) return rc;
+		if ((rc = upload(c->d_sa, bwt->sa, bwt->n_sa * 8, c->stream))) return rc;
+		if ((rc = upload(c->d_pac, pac, (size_t)bns->l_pac / 4 + 1, c->stream))) return rc;
+	}
 	std::vector<DevAnn> anns(bns->n_seqs);
 	for (int i = 0; i < bns->n_seqs; ++i) anns[i] = { bns->anns[i].offset, bns->anns[i].len, bns->anns[i].is_alt };
 	if ((rc = upload(c->d_anns, anns.data(), anns.size() * sizeof(DevAnn), c->stream))) return rc;
@@ -166,6 +171,25 @@ int bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t 
 	return 0;
 }
 
+int bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out)
+{
+	if (!bwt_dev || !bns || !pac_dev || !out || !bwt_dev->bwt || !bwt_dev->sa) return BWAHIP_EINVAL;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+		fprintf(stderr, "[bwahip] no usable HIP device (requested %d of %d)\n", device, n_dev);
+		return BWAHIP_ENODEV;
+	}
+	bwahip_ctx *c = new bwahip_ctx();
+	memset(&c->host, 0, sizeof c->host);
+	c->device = device; c->external_index = true;
+	c->host.bwt = *bwt_dev; c->host.bwt.bwt = nullptr; c->host.bwt.sa = nullptr;   // no host copy of the big arrays
+	c->host.bns = *bns; c->host.pac = nullptr; c->host.owned = false;
+	int rc = ctx_setup(c, bwt_dev, bns, pac_dev);
+	if (rc) { bwahip_destroy(c); return rc; }
+	*out = c;
+	return 0;
+}
+
 int bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out)
 {
 	if (!prefix || !out) return BWAHIP_EINVAL;
@@ -193,6 +217,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
 	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n };
+	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -566,7 +591,6 @@ int bwahip_align_batch(bwahip_ctx *c, const bwahip_opt_t *opt, int n, bwahip_seq
 	if ((rc = run_pipeline(c, opt, false, false))) return rc;
 	return bwahip_batch_download(c, regs_out);
 }
-int bwahip_process_seqs(bwahip_ctx *, const bwahip_opt_t *, int64_t, int, bwahip_seq_t *, const bwahip_pestat_t *) { return BWAHIP_EINVAL; }
 int bwahip_kat_ksw_extend(bwahip_ctx *, int, const int *, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *, int *) { return BWAHIP_EINVAL; }
 
 } // extern "C"

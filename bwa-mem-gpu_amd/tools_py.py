@@ -1,0 +1,143 @@
+"""Python-side tooling for bench.py and the tests: synthetic genomes / reads through libsimgen (ctypes),
+FASTA/FASTQ writers, and the one collective of the system -- the start-up broadcast of the index arrays
+(bwt, sa, pac) from rank 0 over torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_sg = None
+
+
+def _simgen():
+    global _sg
+    if _sg is None:
+        path = os.path.join(_HERE, "tools", "libsimgen.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
+        L = C.CDLL(path)
+        L.simgen_random_bases.argtypes = [C.c_uint64, C.c_int64, C.c_void_p]
+        L.simgen_add_repeats.argtypes = [C.c_uint64, C.c_int64, C.c_void_p]
+        L.simgen_reads.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p]
+        _sg = L
+    return _sg
+
+
+def contig_lengths(total):
+    """Split `total` bases into contigs of at most 150 Mbp (contig length is an int32 in the index)."""
+    n = max(1, -(-total // 150000000))
+    base = total // n
+    return [base + (1 if i < total - base * n else 0) for i in range(n)]
+
+
+def make_genome(seed, lens, repeats=True):
+    """Same bytes as `simgen genome <fa> seed repeat_mode lens...` writes (ASCII ACGTN, contigs concatenated)."""
+    L = _simgen()
+    g = np.empty(int(sum(lens)), dtype=np.uint8)
+    o = 0
+    for c, ln in enumerate(lens):
+        view = g[o:o + ln]
+        L.simgen_random_bases(seed + 1000003 * c, ln, view.ctypes.data)
+        if repeats:
+            L.simgen_add_repeats(seed + 7919 * c, ln, view.ctypes.data)
+        o += ln
+    return g
+
+
+def write_fasta(path, genome, lens, width=60):
+    with open(path, "wb") as f:
+        o = 0
+        for c, ln in enumerate(lens):
+            f.write(b">ctg%d\n" % (c + 1))
+            seq = genome[o:o + ln]
+            full = (ln // width) * width
+            if full:
+                block = np.empty((full // width, width + 1), dtype=np.uint8)
+                block[:, :width] = seq[:full].reshape(-1, width)
+                block[:, width] = 10
+                block.tofile(f)
+            if ln > full:
+                f.write(seq[full:].tobytes() + b"\n")
+            o += ln
+
+
+def make_reads(genome, lens, n, read_len, sub_ppm=10000, indel_ppm=0, n_ppm=0, chim_ppm=0, seed=102, paired=False):
+    """n reads of read_len bases (ASCII), uniform starts, 50 % reverse strand, substitutions to a different base."""
+    L = _simgen()
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(lens, dtype=np.int64), out=off[1:])
+    out = np.empty((n, read_len), dtype=np.uint8)
+    L.simgen_reads(seed, genome.ctypes.data, len(lens), off.ctypes.data, n, read_len, sub_ppm, indel_ppm, n_ppm, chim_ppm,
+                   1 if paired else 0, out.ctypes.data)
+    return out
+
+
+def write_fastq(path, reads, paired_second=None, qual=b"I"):
+    n, rl = reads.shape
+    with open(path, "wb") as f:
+        q = qual * rl
+        for i in range(n):
+            f.write(b"@r%d\n" % i)
+            f.write(reads[i].tobytes())
+            f.write(b"\n+\n" + q + b"\n")
+
+
+# ------------------------------------------------------------------------------------------ index broadcast
+def load_index_arrays(prefix):
+    """Read a stock index file set into numpy arrays + metadata (format: bwt.c:385-462, bntseq.c:65-211)."""
+    raw = np.fromfile(prefix + ".bwt", dtype=np.uint8)
+    hdr = raw[:40].view(np.uint64)
+    bwt = raw[40:]
+    sraw = np.fromfile(prefix + ".sa", dtype=np.uint64)
+    sa_intv, seq_len = int(sraw[5]), int(sraw[6])
+    sa = np.concatenate([np.array([2**64 - 1], dtype=np.uint64), sraw[7:]])
+    with open(prefix + ".ann") as f:
+        l_pac, n_seqs, _seed = f.readline().split()
+        contigs = []
+        for _ in range(int(n_seqs)):
+            name = f.readline().split()[1]
+            o, ln, _ = f.readline().split()
+            contigs.append([name, int(o), int(ln), 0])
+    alt = set()
+    if os.path.exists(prefix + ".alt"):
+        with open(prefix + ".alt") as f:
+            alt = {ln.split("\t")[0].strip() for ln in f if ln and ln[0] != "@"}
+    for c in contigs:
+        c[3] = 1 if c[0] in alt else 0
+    pac = np.fromfile(prefix + ".pac", dtype=np.uint8)[:int(l_pac) // 4 + 1]
+    meta = {"primary": int(hdr[0]), "L2": [0] + [int(x) for x in hdr[1:5]], "seq_len": seq_len, "sa_intv": sa_intv,
+            "n_sa": int(len(sa)), "bwt_words": int(len(bwt) // 4), "l_pac": int(l_pac), "contigs": contigs,
+            "sizes": [int(bwt.nbytes), int(sa.nbytes), int(pac.nbytes)]}
+    return meta, {"bwt": bwt, "sa": sa.view(np.uint8), "pac": pac}
+
+
+def broadcast_index_arrays(dist, torch, prefix, rank, device):
+    """The system's only collective: rank 0 sends the three index arrays, everybody returns (meta, tensors)."""
+    box = [None]
+    arrays = None
+    if rank == 0:
+        meta, arrays = load_index_arrays(prefix)
+        box[0] = meta
+    dist.broadcast_object_list(box, src=0)
+    meta = box[0]
+    tensors = {}
+    for name, size in zip(("bwt", "sa", "pac"), meta["sizes"]):
+        if rank == 0:
+            t = torch.from_numpy(arrays[name]).to(device)
+        else:
+            t = torch.empty(size, dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        tensors[name] = t
+    return meta, tensors
+
+
+def broadcast_index(bw, dist, torch, prefix, rank, local_rank):
+    """Rank 0 (which already holds its own context) only sends; the others build a context on the received
+    device arrays (bwahip_init_device) and must keep the returned tensors alive."""
+    meta, tensors = broadcast_index_arrays(dist, torch, prefix, rank, torch.device(f"cuda:{local_rank}"))
+    if rank == 0:
+        return None
+    torch.cuda.synchronize()
+    ctx = bw.Context.from_device_arrays(meta, tensors["bwt"].data_ptr(), tensors["sa"].data_ptr(), tensors["pac"].data_ptr(), local_rank)
+    return ctx, tensors

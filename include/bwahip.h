@@ -163,6 +163,9 @@ typedef struct bwahip_ctx bwahip_ctx;
  * index arrays (bwt, sa, pac) and the contig table into HBM of HIP device `device` and builds the
  * launch workspaces.  The host arrays are not referenced after it returns. */
 int  bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, int device, bwahip_ctx **out);
+/* Same, but bwt_dev->bwt, bwt_dev->sa and pac_dev already point into HBM of `device` (e.g. filled by an RCCL
+ * broadcast from the rank that loaded the index); the arrays stay owned by the caller and must outlive the ctx. */
+int  bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out);
 /* Convenience: read a stock `bwa index` file set <prefix>.{bwt,sa,pac,ann,amb[,alt]} (bwa.c:402 bwa_idx_load) and init. */
 int  bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out);
 void bwahip_destroy(bwahip_ctx *ctx);
