@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors with the REFERENCE ITSELF (oracle/_ref/bwaref, compiled from the
+reference's own sources by oracle/Makefile).  Runs only where /root/reference exists (the build container);
+the outputs below are data (inputs + expected outputs), never reference source.
+
+  tests/golden/g60k.fa.gz          60 kb three-contig genome with repeats/tandems/N holes (simgen seed 7)
+  tests/golden/g60k.alt            ALT contig list (ctg3 is a diverged copy of part of ctg1)
+  tests/golden/index.sha256        sha256 of the five index files `bwaref index` writes for it
+  tests/golden/se.fq.gz, pe_[12].fq.gz   read sets (mixed error profiles, N's, chimeras, short reads)
+  tests/golden/se.sam.gz, se_all.sam.gz, pe.sam.gz   SAM bodies from the reference's mem_process_seqs
+  tests/golden/se.stages.npz       per-read stage dump (intervals, chains, filtered chains, regions)
+  tests/golden/kat_fm.npz, kat_ksw.npz   known answers for Occ/SA/extend and ksw_extend2/global2/align2
+"""
+import gzip
+import hashlib
+import os
+import subprocess
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+from common import bw  # noqa: E402
+
+REF = common.BWAREF
+TMP = "/tmp/bwahip_golden"
+
+
+def sh(*cmd, **kw):
+    return subprocess.run(list(cmd), check=True, **kw)
+
+
+def gz(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
+        g.write(f.read())
+
+
+def records_to_npz(path, dst):
+    words = np.fromfile(path, dtype=np.int64)
+    np.savez_compressed(dst, words=words)
+
+
+def main():
+    assert os.path.exists("/root/reference/bwamem.c") and os.access(REF, os.X_OK), "needs the reference build (make -C oracle ref)"
+    os.makedirs(TMP, exist_ok=True)
+    fa = f"{TMP}/g60k.fa"
+    # genome: two simgen contigs + an ALT contig that is a 2 % diverged copy of ctg1[5000:9000]
+    bw.make_genome(fa, 7, [40000, 16000], repeats=True)
+    seq = "".join(l.strip() for l in open(fa).read().split(">")[1].split("\n")[1:])
+    rng = np.random.default_rng(3)
+    alt = list(seq[5000:9000])
+    for i in rng.choice(4000, 80, replace=False):
+        alt[i] = "ACGT"[("ACGT".index(alt[i]) + 1 + int(rng.integers(0, 3))) % 4] if alt[i] in "ACGT" else alt[i]
+    with open(fa, "a") as f:
+        f.write(">ctg3 alt_copy\n")
+        a = "".join(alt)
+        for i in range(0, len(a), 60):
+            f.write(a[i:i + 60] + "\n")
+    with open(f"{TMP}/g60k.alt", "w") as f:
+        f.write("ctg3\n")
+    sh(REF, "index", fa, f"{TMP}/g60k")
+    digest = {}
+    for e in ("pac", "ann", "amb", "bwt", "sa"):
+        digest[e] = hashlib.sha256(open(f"{TMP}/g60k.{e}", "rb").read()).hexdigest()
+    with open(f"{HERE}/index.sha256", "w") as f:
+        for e, h in digest.items():
+            f.write(f"{h}  g60k.{e}\n")
+    # reads: mix of profiles, concatenated into one SE file
+    parts = []
+    for k, (n, ln, sub, indel, nn, chim) in enumerate([(120, 150, 10000, 2000, 500, 30000), (80, 100, 20000, 0, 0, 0),
+                                                       (60, 250, 50000, 3000, 500, 30000), (30, 30, 20000, 0, 20000, 0),
+                                                       (10, 17, 0, 0, 0, 0)]):
+        p = f"{TMP}/p{k}.fq"
+        bw.make_reads(fa, p, None, n, ln, sub, indel, nn, 300 + k, chim)
+        parts.append(open(p).read().replace("@r", f"@s{k}_"))
+    open(f"{TMP}/se.fq", "w").write("".join(parts))
+    bw.make_reads(fa, f"{TMP}/pe_1.fq", f"{TMP}/pe_2.fq", 400, 100, 30000, 3000, 1000, 310)
+    with open(f"{TMP}/se.sam", "wb") as f:
+        sh(REF, "mem", f"{TMP}/g60k", f"{TMP}/se.fq", stdout=f, stderr=subprocess.DEVNULL)
+    with open(f"{TMP}/se_all.sam", "wb") as f:
+        sh(REF, "mem", "-a", f"{TMP}/g60k", f"{TMP}/se.fq", stdout=f, stderr=subprocess.DEVNULL)
+    with open(f"{TMP}/pe.sam", "wb") as f:
+        sh(REF, "mem", f"{TMP}/g60k", f"{TMP}/pe_1.fq", f"{TMP}/pe_2.fq", stdout=f, stderr=subprocess.DEVNULL)
+    sh(REF, "stages", f"{TMP}/g60k", f"{TMP}/se.fq", f"{TMP}/se.stages.bin")
+    sh(REF, "katfm", f"{TMP}/g60k", f"{TMP}/kat_fm.bin", "150", "5")
+    sh(REF, "katksw", f"{TMP}/kat_ksw.bin", "120", "7")
+    gz(fa, f"{HERE}/g60k.fa.gz")
+    sh("cp", f"{TMP}/g60k.alt", f"{HERE}/g60k.alt")
+    for n in ("se.fq", "pe_1.fq", "pe_2.fq", "se.sam", "se_all.sam", "pe.sam"):
+        gz(f"{TMP}/{n}", f"{HERE}/{n}.gz")
+    records_to_npz(f"{TMP}/se.stages.bin", f"{HERE}/se.stages.npz")
+    records_to_npz(f"{TMP}/kat_fm.bin", f"{HERE}/kat_fm.npz")
+    records_to_npz(f"{TMP}/kat_ksw.bin", f"{HERE}/kat_ksw.npz")
+    print("golden vectors written to", HERE)
+    sh("ls", "-la", HERE)
+
+
+if __name__ == "__main__":
+    main()
