@@ -169,7 +169,10 @@ def cpu_baseline(tp, bw, prefix, genome, lens, args, workdir):
     ref = os.path.join(ROOT, "oracle", "_ref", "bwaref")
     port = os.path.join(ROOT, "oracle", "bwa_oracle")
     exe, kind = (ref, "reference") if os.access(ref, os.X_OK) else (port, "port")
-    r = subprocess.run([exe, "mem", "-t", str(cores), prefix, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    # -K fixes the batch at 150 M bases; without it the reference's own
+    # chunk_size * n_threads (fastmap.c:304) overflows int at this core count and degenerates to 1-read batches
+    log(f"cpu baseline: {os.path.basename(exe)} on {n} reads with {cores} threads ...")
+    r = subprocess.run([exe, "mem", "-t", str(cores), "-K", "150000000", prefix, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     m = re.search(r"aligned (\d+) reads in ([0-9.]+) s", r.stderr)
     if not m:
         return {"value": None, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"failed: {r.stderr[-200:]}"}

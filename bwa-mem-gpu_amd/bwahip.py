@@ -258,6 +258,15 @@ class Context:
         _check(lib().bwahip_kat_sa(self._h, len(k), k.ctypes.data, out.ctypes.data), "bwahip_kat_sa")
         return out
 
+    def kat_ksw_extend(self, params, q, qoff, t, toff):
+        params = np.ascontiguousarray(params, dtype=np.int32)
+        q, t = np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8)
+        qoff, toff = np.ascontiguousarray(qoff, dtype=np.int64), np.ascontiguousarray(toff, dtype=np.int64)
+        out = np.zeros((len(params), 6), dtype=np.int32)
+        _check(lib().bwahip_kat_ksw_extend(self._h, len(params), params.ctypes.data, q.ctypes.data, qoff.ctypes.data, t.ctypes.data,
+                                           toff.ctypes.data, out.ctypes.data), "bwahip_kat_ksw_extend")
+        return out
+
     def kat_extend(self, ik3, is_back):
         ik3 = np.ascontiguousarray(ik3, dtype=np.uint64)
         is_back = np.ascontiguousarray(is_back, dtype=np.int32)

@@ -642,7 +642,37 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	}
 }
 
+// known-answer kernel: ksw_extend2 on caller-supplied pairs (params per item: qlen,tlen,w,h0,zdrop,end_bonus,o_del,e_del,o_ins,e_ins)
+__global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *params, const uint8_t *q, const int64_t *qoff,
+                                                const uint8_t *t, const int64_t *toff, int *out6)
+{
+	__shared__ uint8_t s_q[MAXQ + 8];
+	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ int8_t s_mat[32];
+	const int r = blockIdx.x, l = lane();
+	if (r >= n) return;
+	const int *p = params + 10 * r;
+	const int qlen = p[0], tlen = p[1];
+	if (l < 25) s_mat[l] = opt.mat[l];
+	for (int i = l; i < qlen; i += 64) s_q[i] = q[qoff[r] + i];
+	for (int i = l; i < tlen; i += 64) s_t[i] = t[toff[r] + i];
+	__syncthreads();
+	Sw sw; sw.mat = s_mat; sw.o_del = p[6]; sw.e_del = p[7]; sw.o_ins = p[8]; sw.e_ins = p[9];
+	int qle, tle, gtle, gscore, max_off;
+	unsigned long long cells = 0;
+	int sc = wave_extend<11>(sw, s_q, 1, qlen, s_t, 1, tlen, p[2], p[5], p[4], p[3], qle, tle, gtle, gscore, max_off, cells);
+	if (l == 0) { int *o = out6 + 6 * r; o[0] = sc; o[1] = qle; o[2] = tle; o[3] = gtle; o[4] = gscore; o[5] = max_off; }
+}
+
 } // namespace
+
+int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff,
+                   int *out6, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_kat_ksw, dim3(n), dim3(64), 0, st, opt, n, params, q, qoff, t, toff, out6);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
 
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 {

@@ -591,6 +591,24 @@ int bwahip_align_batch(bwahip_ctx *c, const bwahip_opt_t *opt, int n, bwahip_seq
 	if ((rc = run_pipeline(c, opt, false, false))) return rc;
 	return bwahip_batch_download(c, regs_out);
 }
-int bwahip_kat_ksw_extend(bwahip_ctx *, int, const int *, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *, int *) { return BWAHIP_EINVAL; }
+int bwahip_kat_ksw_extend(bwahip_ctx *c, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff, int *out6)
+{
+	if (!c || n < 0 || (n && (!params || !q || !qoff || !t || !toff || !out6))) return BWAHIP_EINVAL;
+	if (n == 0) return 0;
+	for (int i = 0; i < n; ++i)
+		if (params[10*i] < 0 || params[10*i] > BWAHIP_MAX_READ_LEN || params[10*i+1] < 0 || params[10*i+1] > BWAHIP_MAX_READ_LEN + 1400 || params[10*i+3] <= 0) return BWAHIP_ECAPACITY;
+	HIP_TRY(hipSetDevice(c->device));
+	bwahip_opt_t o; bwahip_opt_init(&o);
+	DevOpt dopt = make_dev_opt(&o);
+	DevBuf dp, dq, dqo, dt, dto, dout; int rc;
+	if ((rc = upload(dp, params, (size_t)n * 40, c->stream)) || (rc = upload(dq, q, (size_t)qoff[n], c->stream)) || (rc = upload(dqo, qoff, (size_t)(n + 1) * 8, c->stream)) ||
+	    (rc = upload(dt, t, (size_t)toff[n], c->stream)) || (rc = upload(dto, toff, (size_t)(n + 1) * 8, c->stream)) || (rc = dout.ensure((size_t)n * 24))) goto done;
+	rc = launch_kat_ksw(dopt, n, dp.as<int>(), dq.as<uint8_t>(), dqo.as<int64_t>(), dt.as<uint8_t>(), dto.as<int64_t>(), dout.as<int>(), c->stream);
+	if (!rc && hipMemcpyAsync(out6, dout.p, (size_t)n * 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+done:
+	dp.release(); dq.release(); dqo.release(); dt.release(); dto.release(); dout.release();
+	return rc;
+}
 
 } // extern "C"

@@ -137,3 +137,24 @@ def test_extend_known_answers_vs_oracle_lib(ctx, small_index):
     assert (sizes == 1).sum() > 100
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert len(bad) == 0, f"{len(bad)} of {len(want)} extends differ; first: ik={iks[bad[0]]} back={backs[bad[0]]} got={got[bad[0]]} want={want[bad[0]]}"
+
+
+def test_ksw_extend_known_answers_from_reference(ctx):
+    """Wavefront ksw_extend2 vs the reference's own results (tests/golden/kat_ksw.npz): narrow and wide bands,
+    z-drop on/off, asymmetric gap costs, ambiguous bases, query lengths 1..250."""
+    words = np.load(os.path.join(common.GOLDEN, "kat_ksw.npz"))["words"]
+    params, qs, ts, want = [], [], [], []
+    for tag, v in bw.parse_records(words):
+        if tag != 20:
+            continue
+        v = [int(x) for x in v]
+        qlen, tlen = v[0], v[1]
+        if v[6:10] != [6, 1, 6, 1] and v[6:10] != [4, 2, 7, 1]:
+            continue
+        params.append(v[:10]); qs.append(v[10:10 + qlen]); ts.append(v[10 + qlen:10 + qlen + tlen]); want.append(v[10 + qlen + tlen:])
+    qoff = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.int64)
+    toff = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.int64)
+    got = ctx.kat_ksw_extend(np.array(params), np.concatenate(qs), qoff, np.concatenate(ts), toff)
+    assert len(want) >= 100
+    bad = [i for i in range(len(want)) if list(got[i]) != want[i]]
+    assert not bad, f"{len(bad)} of {len(want)} differ; first {bad[0]}: params={params[bad[0]]} got={list(got[bad[0]])} want={want[bad[0]]}"
