@@ -145,6 +145,8 @@ def main():
             "per_read": {"bwt_extend": round(counters["extend"] / args.reads, 1), "occ_blocks": round(counters["blocks"] / args.reads, 1),
                          "sa_lookups": round(counters["sa"] / args.reads, 2), "lf_steps": round(counters["lf"] / args.reads, 1),
                          "dp_cells": round(counters["cells"] / args.reads, 1)},
+            "tail_us": {k: round(v / 100.0, 1) for k, v in counters.items() if k.endswith("_max")},
+            "tail_counts": {"max_seeds_per_read": counters.get("max_seeds"), "max_chains_per_read": counters.get("max_chains")},
             "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k1, 3)},

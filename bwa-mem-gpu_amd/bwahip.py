@@ -243,7 +243,8 @@ class Context:
     def counters(self):
         buf = (C.c_uint64 * 16)()
         _check(lib().bwahip_batch_counters(self._h, buf, 16), "bwahip_batch_counters")
-        names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells"]
+        names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells", "_7", "chain_build_max", "chain_sort_max", "chain_flt_max",
+                 "chain_write_max", "max_seeds", "max_chains", "ext_max", "ext_dedup_max"]
         return {k: int(buf[i]) for i, k in enumerate(names)}
 
     def kat_occ4(self, k):

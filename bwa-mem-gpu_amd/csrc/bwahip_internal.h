@@ -113,6 +113,7 @@ struct ChainLaunch {
 	DevChain *chains; DevSeed *chain_seeds; int *chain_n, *kept_seeds;
 	// optional stage dump of the unfiltered chains (nullptr = off)
 	DevChain *dbg_chains; DevSeed *dbg_seeds; int *dbg_chain_n;
+	unsigned long long *counters;
 };
 int launch_chain(const ChainLaunch &a, hipStream_t st);
 

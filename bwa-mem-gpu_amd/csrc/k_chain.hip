@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 	}
 	const float frac_rep = (float)l_rep / len;                  // bwamem.c:317
 
+	const unsigned long long t_0 = wall_clock64();
 	// greedy chaining (bwamem.c:280-308)
 	c.root = bt_new(c, 0);
 	for (int si = 0; si < S; ++si) {
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 			bt_put(c, c.n_chains++);
 		}
 	}
+	const unsigned long long t_1 = wall_clock64();
 	int n_chn = bt_inorder(c, c.ord);                           // bwamem.c:311-315
 	if (a.dbg_chain_n) {                                        // stage dump: chains before filtering
 		a.dbg_chain_n[r] = n_chn;
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 	n_chn = k;
 	if (n_chn == 0) return;
 	isort_weight(c, n_chn, c.ord);
+	const unsigned long long t_2 = wall_clock64();
 	// NB: `first` and the kept list hold positions in the sorted array, as in the reference
 	int n_keep = 0;
 	c.kept[c.ord[0]] = 3;
@@ -359,9 +362,14 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 		int ci = c.ord[i];
 		if (c.kept[ci] != 0) { c.ord[n_out++] = ci; tot += c.cw[ci].n; }
 	}
+	const unsigned long long t_3 = wall_clock64();
 	write_chains(c, a.ix, n_out, c.ord, frac_rep, true, a.chains + sb, a.chain_seeds + sb);
 	a.chain_n[r] = n_out;
 	a.kept_seeds[r] = tot;
+	if (a.counters) {                                           // phase maxima in 10 ns ticks (profiling aid)
+		atomicMax(&a.counters[8], t_1 - t_0); atomicMax(&a.counters[9], t_2 - t_1); atomicMax(&a.counters[10], t_3 - t_2);
+		atomicMax(&a.counters[11], wall_clock64() - t_3); atomicMax(&a.counters[12], (unsigned long long)S); atomicMax(&a.counters[13], (unsigned long long)n_chn);
+	}
 }
 
 } // namespace

@@ -25,18 +25,36 @@ constexpr int MAXT = BWAHIP_MAX_READ_LEN + 2 * 200 + 1024;   // reference window
 constexpr int LOW = -0x60000000;                             // below every real DP value, and LOW - 1000*e stays above INT_MIN
 
 __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ int wmax(int v) { for (int d = 32; d; d >>= 1) { int o = __shfl_xor(v, d); v = v > o ? v : o; } return v; }
-__device__ __forceinline__ int wmin(int v) { for (int d = 32; d; d >>= 1) { int o = __shfl_xor(v, d); v = v < o ? v : o; } return v; }
+// ---- wavefront reductions / scan on DPP (VALU only).  The tail of this kernel is one wavefront walking the
+// rows of one read, so the dependent latency of a row matters: a 6-step ds_bpermute reduction costs ~700
+// cycles, the same reduction on DPP row shifts / row broadcasts ~50.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_or(int v, int fill)
+{
+	return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);   // lanes without a source keep `fill`
+}
+// inclusive prefix max over the 64 lanes (lane i gets max of lanes 0..i); ident = value below every input
+__device__ __forceinline__ int wscan_incl_max(int v, int ident)
+{
+	int t;
+	t = dpp_or<0x111, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:1
+	t = dpp_or<0x112, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:2
+	t = dpp_or<0x114, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:4
+	t = dpp_or<0x118, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:8   -> scan inside each row of 16
+	t = dpp_or<0x142, 0xa>(v, ident); v = v > t ? v : t;      // row_bcast15 into rows 1,3
+	t = dpp_or<0x143, 0xc>(v, ident); v = v > t ? v : t;      // row_bcast31 into rows 2,3
+	return v;
+}
+__device__ __forceinline__ int wmax(int v) { return __builtin_amdgcn_readlane(wscan_incl_max(v, (int)0x80000000), 63); }
+__device__ __forceinline__ int wmin(int v) { return -wmax(-v); }          // callers never pass INT_MIN
 __device__ __forceinline__ int wsum(int v) { for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d); return v; }
 __device__ __forceinline__ int64_t wmax64(int64_t v) { for (int d = 32; d; d >>= 1) { int64_t o = __shfl_xor(v, d); v = v > o ? v : o; } return v; }
 __device__ __forceinline__ int64_t wmin64(int64_t v) { for (int d = 32; d; d >>= 1) { int64_t o = __shfl_xor(v, d); v = v < o ? v : o; } return v; }
 // exclusive prefix max over lanes (lane 0 gets `ident`)
 __device__ __forceinline__ int wscan_excl_max(int v, int ident)
 {
-	const int l = lane();
-	for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (l >= d) v = v > o ? v : o; }
-	int p = __shfl_up(v, 1);
-	return l == 0 ? ident : p;
+	const int inc = wscan_incl_max(v, ident);
+	const int p = __builtin_amdgcn_update_dpp(ident, inc, 0x138, 0xf, 0xf, false);   // wave_shr:1
+	return p;
 }
 
 struct Sw { const int8_t *mat; int o_del, e_del, o_ins, e_ins; };
@@ -115,7 +133,7 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 			run = run > u[c] ? run : u[c];
 		}
 		// shift: eh[j+1].h = H(i,j) (ksw.c:432 p->h = h1), eh[beg].h = first-column value, eh[end] = {h1, 0}
-		const int up = __shfl_up(h[CPL - 1], 1);
+		const int up = __builtin_amdgcn_update_dpp(0, h[CPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
 #pragma unroll
 		for (int c = CPL - 1; c >= 0; --c) {
 			const int j = j0 + c;
@@ -213,7 +231,7 @@ __device__ int wave_global_score(const Sw &sw, const uint8_t *q, int qs, int qle
 			}
 			run = run > u[c] ? run : u[c];
 		}
-		const int up = __shfl_up(h[CPL - 1], 1);
+		const int up = __builtin_amdgcn_update_dpp(0, h[CPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
 #pragma unroll
 		for (int c = CPL - 1; c >= 0; --c) {
 			const int j = j0 + c;
@@ -350,6 +368,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	int *srt = a.srt + 2 * sb;                                  // [0..n): seed index in ascending (score,idx) order; [n..2n): skipped flag
 	int n_av = 0;
 	unsigned long long cells = 0;
+	const unsigned long long t_0 = wall_clock64();
 	Sw sw; sw.mat = s_mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins;
 	if (l < 25) s_mat[l] = opt.mat[l];
 	for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
@@ -497,6 +516,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 		if (l == 0) a.dbg_reg_n[r] = n_av;
 	}
 
+	const unsigned long long t_1 = wall_clock64();
 	// ---- mem_sort_dedup_patch (bwamem.c:444-496) + is_alt (bwamem.c:1091-1095).  The scalar logic is replicated
 	// in every lane (identical reads of av[]), stores are done by lane 0; the rare banded global alignment is
 	// collective.  The sort permutes an index array; the list is then gathered into that order.
@@ -639,6 +659,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	if (l == 0) {
 		a.reg_n[r] = n;
 		if (cells) atomicAdd(&a.counters[CNT_CELLS], cells);
+		atomicMax(&a.counters[14], t_1 - t_0); atomicMax(&a.counters[15], wall_clock64() - t_1);
 	}
 }
 

@@ -372,6 +372,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		cl.nodes_ = c->d_nodes.as<BtNodeOpaque>(); cl.stack = c->d_stack.as<int>();
 		cl.chains = c->d_chains.as<DevChain>(); cl.chain_seeds = c->d_chain_seeds.as<DevSeed>();
 		cl.chain_n = c->d_chain_n.as<int>(); cl.kept_seeds = c->d_kept_seeds.as<int>();
+		cl.counters = counters;
 		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }
 		if (timed) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
 		if ((rc = launch_chain(cl, c->stream))) return rc;
