@@ -114,8 +114,11 @@ struct ChainLaunch {
 	// optional stage dump of the unfiltered chains (nullptr = off)
 	DevChain *dbg_chains; DevSeed *dbg_seeds; int *dbg_chain_n;
 	unsigned long long *counters;
+	int *flt;                                    // 8 ints per seed slot: per-position data for k_chain_flt
+	int *heavy_list, *heavy_count;               // reads whose overlap filter is deferred to k_chain_flt
 };
 int launch_chain(const ChainLaunch &a, hipStream_t st);
+int launch_chain_flt(const ChainLaunch &a, hipStream_t st);
 
 struct ExtLaunch {
 	DevIndex ix; DevOpt opt;

@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int BT_T = 6, BT_MAXK = 2 * BT_T - 1;              // kbtree.h:59 with sizeof(mem_chain_t) = 32
+constexpr int FLT_SEQ_MAX = 32;                              // more chains than this: filter in k_chain_flt
 
 struct BtNode { int is_internal, n; int key[BT_MAXK]; int ptr[BT_MAXK + 1]; int pad; };
 static_assert(sizeof(BtNode) == sizeof(BtNodeOpaque), "BtNode layout");
@@ -321,6 +322,20 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 	if (n_chn == 0) return;
 	isort_weight(c, n_chn, c.ord);
 	const unsigned long long t_2 = wall_clock64();
+	if (n_chn > FLT_SEQ_MAX && a.heavy_list) {
+		// many chains: the O(n^2) overlap filter runs wavefront-parallel in k_chain_flt; leave it the per-position data
+		int *fb = a.flt + 8 * sb, *fe = fb + S, *fw = fe + S;
+		for (int i = 0; i < n_chn; ++i) {
+			const int ci = c.ord[i];
+			fb[i] = chn_beg(c, ci) | (a.ix.anns[c.cw[ci].rid].is_alt ? 1 << 30 : 0);
+			fe[i] = chn_end(c, ci);
+			fw[i] = c.wts[ci];
+		}
+		a.chain_n[r] = -n_chn;                                  // pending marker
+		a.heavy_list[atomicAdd(a.heavy_count, 1)] = r;
+		if (a.counters) { atomicMax(&a.counters[8], t_1 - t_0); atomicMax(&a.counters[9], t_2 - t_1); atomicMax(&a.counters[12], (unsigned long long)S); atomicMax(&a.counters[13], (unsigned long long)n_chn); }
+		return;
+	}
 	// NB: `first` and the kept list hold positions in the sorted array, as in the reference
 	int n_keep = 0;
 	c.kept[c.ord[0]] = 3;
@@ -372,7 +387,116 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_chain_flt: the pairwise overlap filter of mem_chain_flt (bwamem.c:350-392) for reads with many chains,
+// one read per wavefront.  For chain i (sequential, heavier first) the kept chains are tested 64 at a time;
+// the reference's sequential semantics -- stop at the first kept chain that shadows i, having set `first`
+// on every significantly overlapping kept chain up to and including it -- are recovered with ballots.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chain_flt(ChainLaunch a)
+{
+	const int l = (int)(threadIdx.x & 63);
+	const int n_heavy = *a.heavy_count;
+	for (int hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+		const int r = a.heavy_list[hi];
+		const int64_t sb = a.seed_base[r];
+		const int S = (int)(a.seed_base[r + 1] - sb), len = (int)(a.off[r + 1] - a.off[r]);
+		const int n = -a.chain_n[r];
+		const unsigned long long t_0 = wall_clock64();
+		int *ord = a.ord + sb, *nxt = a.nxt + sb;
+		ChainW *cw = reinterpret_cast<ChainW*>(a.cw_) + sb;
+		const DevSeed *seeds = a.seeds + sb;
+		int *fb = a.flt + 8 * sb, *fe = fb + S, *fw = fe + S, *Kb = fw + S, *Ke = Kb + S, *Kw = Ke + S, *ooff = Kw + S, *oidx = ooff + S;
+		int *kept = a.kept + sb, *Kfirst = a.first + sb;         // kept: by sorted position; Kfirst: by kept index
+		int *kmap = a.keep_list + sb;                            // sorted position -> kept index (-1: not in the kept list)
+		for (int i = l; i < n; i += 64) { kept[i] = 0; kmap[i] = -1; }
+		__threadfence_block(); __syncthreads();
+		int nk = 0;
+		if (l == 0) { kept[0] = 3; kmap[0] = 0; Kb[0] = fb[0]; Ke[0] = fe[0]; Kw[0] = fw[0]; Kfirst[0] = -1; }
+		nk = 1;
+		__threadfence_block(); __syncthreads();
+		for (int i = 1; i < n; ++i) {
+			const int bi_ = fb[i], ei = fe[i], wi = fw[i];
+			const int bi = bi_ & 0x3fffffff; const bool i_alt = (bi_ >> 30) & 1;
+			bool large = false, broke = false;
+			for (int base = 0; base < nk && !broke; base += 64) {
+				const int kk = base + l;
+				bool sig = false, brk = false;
+				if (kk < nk) {
+					const int bj_ = Kb[kk], ej = Ke[kk], wj = Kw[kk];
+					const int bj = bj_ & 0x3fffffff; const bool j_alt = (bj_ >> 30) & 1;
+					const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+					if (e_min > b_max && (!j_alt || i_alt)) {
+						const int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
+						if ((float)(e_min - b_max) >= (float)min_l * a.opt.mask_level && min_l < a.opt.max_chain_gap) {
+							sig = true;
+							if ((float)wi < (float)wj * a.opt.drop_ratio && wj - wi >= a.opt.min_seed_len << 1) brk = true;
+						}
+					}
+				}
+				const unsigned long long m_brk = __ballot(brk), m_sig = __ballot(sig);
+				int upto = 64;                                  // lanes < upto take part
+				if (m_brk) { upto = __ffsll((long long)m_brk); broke = true; }   // includes the breaking lane
+				const unsigned long long in = upto >= 64 ? ~0ull : ((1ull << upto) - 1);
+				if (m_sig & in) large = true;
+				if (sig && l < upto && Kfirst[kk] < 0) Kfirst[kk] = i;
+			}
+			if (!broke) {
+				if (l == 0) { kept[i] = large ? 2 : 3; kmap[i] = nk; Kb[nk] = bi_; Ke[nk] = ei; Kw[nk] = wi; Kfirst[nk] = -1; }
+				++nk;
+			}
+			__threadfence_block(); __syncthreads();
+		}
+		for (int kk = l; kk < nk; kk += 64) { const int f = Kfirst[kk]; if (f >= 0) kept[f] = 1; }   // bwamem.c:376-379
+		__threadfence_block(); __syncthreads();
+		if (l == 0) {
+			int i, k = 0;
+			if (a.opt.max_chain_extend < n) {                     // bwamem.c:380-385 (no-op at the default 1<<30)
+				for (i = 0; i < n; ++i) { const int kp = kept[i]; if (kp == 0 || kp == 3) continue; if (++k >= a.opt.max_chain_extend) break; }
+				for (; i < n; ++i) if (kept[i] < 3) kept[i] = 0;
+			}
+			int n_out = 0, tot = 0;
+			for (i = 0; i < n; ++i) if (kept[i] != 0) { oidx[n_out] = i; ooff[n_out] = tot; tot += cw[ord[i]].n; ++n_out; }
+			a.chain_n[r] = n_out; a.kept_seeds[r] = tot;
+		}
+		__threadfence_block(); __syncthreads();
+		const int n_out = a.chain_n[r];
+		// frac_rep (bwamem.c:272-279, 317)
+		int l_rep = 0;
+		{
+			const DevIntv *iv = a.intv + (size_t)r * a.cap;
+			int ni = a.intv_n[r], b = 0, e = 0;
+			for (int t = 0; t < ni; ++t) {
+				if (iv[t].x2 <= (uint64_t)a.opt.max_occ) continue;
+				int sbq = (int)(iv[t].info >> 32), seq = (int)(uint32_t)iv[t].info;
+				if (sbq > e) { l_rep += e - b; b = sbq; e = seq; }
+				else e = e > seq ? e : seq;
+			}
+			l_rep += e - b;
+		}
+		const float frac_rep = (float)l_rep / len;
+		for (int k = l; k < n_out; k += 64) {                     // one chain per lane: header + seed copy
+			const int i = oidx[k], ci = ord[i];
+			DevChain h;
+			h.pos = cw[ci].pos; h.seed_off = ooff[k]; h.n = cw[ci].n; h.rid = cw[ci].rid;
+			h.w = fw[i]; h.kept = kept[i]; h.first = kmap[i] >= 0 ? Kfirst[kmap[i]] : -1; h.is_alt = (fb[i] >> 30) & 1; h.frac_rep = frac_rep;
+			a.chains[sb + k] = h;
+			int so = ooff[k];
+			for (int s = cw[ci].head; s >= 0; s = nxt[s]) a.chain_seeds[sb + so++] = seeds[s];
+		}
+		if (l == 0 && a.counters) atomicMax(&a.counters[10], wall_clock64() - t_0);
+		__syncthreads();
+	}
+}
+
 } // namespace
+
+int launch_chain_flt(const ChainLaunch &a, hipStream_t st)
+{
+	if (a.n_reads <= 0 || !a.heavy_list) return 0;
+	hipLaunchKernelGGL(k_chain_flt, dim3(4096), dim3(64), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
 
 int launch_chain(const ChainLaunch &a, hipStream_t st)
 {

@@ -63,7 +63,7 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy;
 	int intv_cap = 96;
 	int64_t total_seeds = 0, total_regs = 0;
 	hipEvent_t ev[16];
@@ -216,7 +216,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n };
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -373,9 +373,13 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		cl.chains = c->d_chains.as<DevChain>(); cl.chain_seeds = c->d_chain_seeds.as<DevSeed>();
 		cl.chain_n = c->d_chain_n.as<int>(); cl.kept_seeds = c->d_kept_seeds.as<int>();
 		cl.counters = counters;
+		if ((rc = c->d_flt.ensure(T * 32)) || (rc = c->d_heavy.ensure((size_t)(n + 4) * 4))) return rc;
+		cl.flt = c->d_flt.as<int>(); cl.heavy_list = c->d_heavy.as<int>() + 4; cl.heavy_count = c->d_heavy.as<int>();
+		HIP_TRY(hipMemsetAsync(c->d_heavy.p, 0, 16, c->stream));
 		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }
 		if (timed) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
 		if ((rc = launch_chain(cl, c->stream))) return rc;
+		if ((rc = launch_chain_flt(cl, c->stream))) return rc;
 		STAGE_LOG("k_chain");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
 		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_kept_seeds.as<int>(), c->d_reg_base.as<int64_t>(), n);
