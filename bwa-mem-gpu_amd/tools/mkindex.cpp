@@ -8,7 +8,7 @@
 //   .bwt  primary, L2[1..4], Occ-interleaved BWT of  fwd + revcomp          (bwtindex.c:64-172, bwt.c:385)
 //   .sa   every 32nd suffix-array value                                      (bwt.c:62-84, 396-407)
 // The suffix array is built by a parallel sort on 32-base packed keys with deeper comparison on ties
-// (fine up to a few hundred Mbp of mostly non-repetitive sequence; hg38-scale needs the GPU builder).
+// (memory ~ 20 bytes per text symbol: hg38-scale text, 6.2 G symbols, needs ~130 GB of RAM and a many-core host).
 //
 //   mkindex <in.fa> <prefix>
 #include <stdio.h>
@@ -105,24 +105,30 @@ int main(int argc, char **argv)
 
 	// ---- text = forward + reverse complement ----
 	const int64_t N = l_pac * 2;
-	if (N >= (int64_t)0xffffffffLL) { fprintf(stderr, "mkindex: sequence too long for the CPU builder\n"); return 1; }
 	base.resize((size_t)N);
+#pragma omp parallel for schedule(static)
 	for (int64_t i = 0; i < l_pac; ++i) base[(size_t)(N - 1 - i)] = 3 - base[(size_t)i];
 	std::vector<uint64_t> w((size_t)(N + 31) / 32 + 2, 0);            // 32 bases per word, first base on top
-	for (int64_t i = 0; i < N; ++i) w[(size_t)(i >> 5)] |= (uint64_t)base[(size_t)i] << ((~i & 31) << 1);
+#pragma omp parallel for schedule(static)
+	for (int64_t wi = 0; wi < (N + 31) / 32; ++wi) {
+		uint64_t x = 0;
+		const int64_t lo = wi * 32, hi = lo + 32 < N ? lo + 32 : N;
+		for (int64_t i = lo; i < hi; ++i) x |= (uint64_t)base[(size_t)i] << ((~i & 31) << 1);
+		w[(size_t)wi] = x;
+	}
 	auto key_at = [&](int64_t i) -> uint64_t {                          // 32 bases from i, zero padded past N
 		int sh = (int)(i & 31) << 1;
 		uint64_t a = w[(size_t)(i >> 5)];
 		return sh ? (a << sh) | (w[(size_t)(i >> 5) + 1] >> (64 - sh)) : a;
 	};
-	struct Ent { uint64_t key; uint32_t idx; };
+	struct Ent { uint64_t key; uint64_t idx; };                         // 16 bytes either way; 64-bit idx admits hg38-scale text (6.2 G symbols)
 	std::vector<Ent> sa((size_t)N);
 #pragma omp parallel for schedule(static)
 	for (int64_t i = 0; i < N; ++i) {
 		uint64_t k = key_at(i);
 		int64_t rem = N - i;
 		if (rem < 32) k &= ~0ull << ((32 - rem) << 1);
-		sa[(size_t)i] = { k, (uint32_t)i };
+		sa[(size_t)i] = { k, (uint64_t)i };
 	}
 	auto less = [&](const Ent &a, const Ent &b) -> bool {
 		if (a.key != b.key) return a.key < b.key;
@@ -146,30 +152,51 @@ int main(int argc, char **argv)
 	// ---- BWT, Occ interleave, sampled SA ----
 	// full suffix array rows: row 0 = "$" (position N), row r+1 = sa[r]
 	uint64_t primary = 0, L2[5] = { 0, 0, 0, 0, 0 };
-	for (int64_t i = 0; i < N; ++i) ++L2[1 + base[(size_t)i]];
-	for (int i = 2; i <= 4; ++i) L2[i] += L2[i - 1];
+	{
+		uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma omp parallel for schedule(static) reduction(+:c0,c1,c2,c3)
+		for (int64_t i = 0; i < N; ++i) { uint8_t b = base[(size_t)i]; c0 += b == 0; c1 += b == 1; c2 += b == 2; c3 += b == 3; }
+		L2[1] = c0; L2[2] = c0 + c1; L2[3] = c0 + c1 + c2; L2[4] = c0 + c1 + c2 + c3;
+	}
 	std::vector<uint8_t> bw((size_t)N);                                  // '$'-removed BWT
 	{
-		int64_t o = 0;
-		bw[(size_t)o++] = base[(size_t)N - 1];                           // row 0: char before '$'
+		int64_t rp = -1;                                                 // the row whose BWT char is '$'
+#pragma omp parallel for schedule(static)
+		for (int64_t r = 0; r < N; ++r) if (sa[(size_t)r].idx == 0) rp = r;
+		primary = (uint64_t)rp + 1;
+		bw[0] = base[(size_t)N - 1];                                     // row 0: char before '$'
+#pragma omp parallel for schedule(static)
 		for (int64_t r = 0; r < N; ++r) {
-			uint32_t p = sa[(size_t)r].idx;
-			if (p == 0) primary = (uint64_t)r + 1;                       // this row's BWT char is '$'
-			else bw[(size_t)o++] = base[p - 1];
+			if (r == rp) continue;
+			const uint64_t p = sa[(size_t)r].idx;
+			bw[(size_t)(r < rp ? r + 1 : r)] = base[p - 1];
 		}
 	}
 	{
-		const uint64_t n_occ = (uint64_t)(N + 127) / 128 + 1;
+		const uint64_t n_blk = (uint64_t)(N + 127) / 128, n_occ = n_blk + 1;
 		const uint64_t bwt_words = (uint64_t)(N + 15) / 16 + n_occ * 8;
 		std::vector<uint32_t> buf((size_t)bwt_words, 0);
-		uint64_t c[4] = { 0, 0, 0, 0 }, k = 0;
-		for (int64_t i = 0; i < N; ++i) {
-			if (i % 128 == 0) { memcpy(&buf[(size_t)k], c, 32); k += 8; }
-			if (i % 16 == 0) ++k;
-			buf[(size_t)k - 1] |= (uint32_t)bw[(size_t)i] << ((~i & 15) << 1);
-			++c[bw[(size_t)i]];
+		std::vector<uint64_t> cnt((size_t)(n_blk + 1) * 4, 0);           // counts before each 128-base block
+#pragma omp parallel for schedule(static)
+		for (int64_t b = 0; b < (int64_t)n_blk; ++b) {
+			uint64_t c[4] = { 0, 0, 0, 0 };
+			const int64_t lo = b * 128, hi = lo + 128 < N ? lo + 128 : N;
+			for (int64_t i = lo; i < hi; ++i) ++c[bw[(size_t)i]];
+			memcpy(&cnt[(size_t)(b + 1) * 4], c, 32);
 		}
-		memcpy(&buf[(size_t)k], c, 32);
+		for (uint64_t b = 1; b <= n_blk; ++b) for (int t = 0; t < 4; ++t) cnt[b * 4 + t] += cnt[(b - 1) * 4 + t];
+#pragma omp parallel for schedule(static)
+		for (int64_t b = 0; b < (int64_t)n_blk; ++b) {                   // block b: 8 words of counts, then up to 8 words of bases
+			const int64_t lo = b * 128, hi = lo + 128 < N ? lo + 128 : N;
+			uint64_t k = (uint64_t)b * 16 - 0;
+			// words before block b: b*(8+8) when all earlier blocks are full (only the last block can be short)
+			memcpy(&buf[(size_t)k], &cnt[(size_t)b * 4], 32);
+			for (int64_t i = lo; i < hi; ++i) buf[(size_t)(k + 8 + ((i - lo) >> 4))] |= (uint32_t)bw[(size_t)i] << ((~i & 15) << 1);
+		}
+		{   // the trailing count block (bwtindex.c:169)
+			const uint64_t k = (uint64_t)(N + 15) / 16 + n_blk * 8;
+			memcpy(&buf[(size_t)k], &cnt[(size_t)n_blk * 4], 32);
+		}
 		FILE *f = fopen((prefix + ".bwt").c_str(), "wb");
 		fwrite(&primary, 8, 1, f); fwrite(L2 + 1, 8, 4, f);
 		fwrite(buf.data(), 4, buf.size(), f);
