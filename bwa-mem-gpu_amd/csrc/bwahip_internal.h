@@ -128,6 +128,7 @@ struct ExtLaunch {
 	DevReg *regs; int *reg_n;                    // final regions of read r at regs[reg_base[r] .. +reg_n[r])
 	DevReg *dbg_regs; int *dbg_reg_n;            // optional: regions before mem_sort_dedup_patch
 	DevReg *tmp_regs;                            // spare list of the same size as regs (sort gather)
+	const int *kept_seeds; int *perm, *perm_counts;   // launch order: reads with many seeds first (nullptr = identity)
 	int *srt;                                    // per-seed-slot scratch (sorted seed order), 2 ints per slot
 	unsigned long long *counters; int *err;
 };

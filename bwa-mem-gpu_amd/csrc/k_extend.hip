@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ int s_stk[3 * 80];
-	const int r = blockIdx.x, l = lane();
+	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x, l = lane();   // heavy reads are scheduled first (k_order)
 	const DevOpt &opt = a.opt;
 	const DevIndex &ix = a.ix;
 	const int l_query = (int)(a.off[r + 1] - a.off[r]);
@@ -663,6 +663,16 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	}
 }
 
+// Scheduling aid: reads with many seeds to extend go to the front of the launch order so that the long
+// ones start first and the short ones fill in behind them (the order has no effect on results).
+__global__ void k_order(int n, const int *kept_seeds, int *perm, int *counts)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	if (kept_seeds[r] >= 64) perm[atomicAdd(&counts[0], 1)] = r;
+	else perm[n - 1 - atomicAdd(&counts[1], 1)] = r;
+}
+
 // known-answer kernel: ksw_extend2 on caller-supplied pairs (params per item: qlen,tlen,w,h0,zdrop,end_bonus,o_del,e_del,o_ins,e_ins)
 __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *params, const uint8_t *q, const int64_t *qoff,
                                                 const uint8_t *t, const int64_t *toff, int *out6)
@@ -698,6 +708,10 @@ int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 {
 	if (a.n_reads <= 0) return 0;
+	if (a.perm) {
+		(void)hipMemsetAsync(a.perm_counts, 0, 8, st);
+		hipLaunchKernelGGL(k_order, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.kept_seeds, a.perm, a.perm_counts);
+	}
 	// columns 0..max_len must fit in 64 lanes x CPL registers
 	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend<3>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend<5>, dim3(a.n_reads), dim3(64), 0, st, a);
