@@ -94,8 +94,21 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 	w = w < max_del ? w : max_del;
 	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
+	int scn[CPL];                                                // substitution scores of the next row (prefetched from LDS)
+	{
+		const int tb0 = tlen > 0 ? t[0] : 4;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) scn[c] = sw.mat[tb0 * 5 + qv[c]];
+	}
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = t[i * ts];
+		int scv[CPL];
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) scv[c] = scn[c];
+		{
+			const int tbn = i + 1 < tlen ? t[(i + 1) * ts] : 4;   // issued now, consumed next iteration
+#pragma unroll
+			for (int c = 0; c < CPL; ++c) scn[c] = sw.mat[tbn * 5 + qv[c]];
+		}
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -107,8 +120,7 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 		for (int c = 0; c < CPL; ++c) {
 			const int j = j0 + c;
 			const bool inb = j >= beg && j < end;
-			const int sc = sw.mat[tb * 5 + qv[c]];
-			M[c] = Hs[c] ? Hs[c] + sc : 0;                         // ksw.c:433
+			M[c] = Hs[c] ? Hs[c] + scv[c] : 0;                     // ksw.c:433
 			int tI = M[c] - oe_ins; tI = tI > 0 ? tI : 0;
 			u[c] = inb ? tI + j * e_ins : NEG;
 			P = P > u[c] ? P : u[c];
@@ -166,9 +178,15 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 				if (best - m - ((mj - best_j) - (i - best_i)) * e_ins > zdrop) break;
 			}
 		}
-		// band trimming (ksw.c:466-469); `end` itself is a candidate for the backward scan
-		int fz = wmin(firstnz < end ? firstnz : end);            // first non-zero in [beg,end), else end
-		int lz = wmax(lastnz);                                    // last non-zero in [beg,end], else -1
+		// band trimming (ksw.c:466-469); `end` itself is a candidate for the backward scan.  Columns grow with the
+		// lane index, so the first / last lane holding a non-zero cell holds the first / last such column.
+		const unsigned long long nzm = __ballot(lastnz >= 0);
+		int fz = end, lz = -1;
+		if (nzm) {
+			fz = __builtin_amdgcn_readlane(firstnz, __ffsll((long long)nzm) - 1);
+			lz = __builtin_amdgcn_readlane(lastnz, 63 - __clzll((long long)nzm));
+			fz = fz < end ? fz : end;                             // first non-zero in [beg,end), else end
+		}
 		const int nbeg = fz;
 		if (lz < nbeg) lz = nbeg - 1;
 		beg = nbeg;
