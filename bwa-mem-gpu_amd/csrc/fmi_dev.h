@@ -147,6 +147,69 @@ __device__ __forceinline__ int group8_extend_c(const DevIndex &ix, const Bi &ik,
 	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;
 }
 
+// bwt_extend by ONE quad (16 reads per wavefront): the quad fetches the block of k and then the block of l
+// (two independent 16-byte loads per lane, both in flight together).  Same result as group8_extend_c.
+__device__ __forceinline__ int quad_extend_c(const DevIndex &ix, const Bi &ik, int is_back, int c, bool live, Bi &o)
+{
+	uint64_t xa = is_back ? ik.x0 : ik.x1;
+	uint64_t xb = is_back ? ik.x1 : ik.x0;
+	uint64_t k = xa - 1, l = k + ik.x2;
+	uint64_t tk[4], tl[4];
+	quad_occ4(ix, k, live, tk);
+	quad_occ4(ix, l, live, tl);
+	uint64_t s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+	uint64_t lo = L2_at(ix, c) + 1 + sel4(c, tk[0], tk[1], tk[2], tk[3]);
+	uint64_t sz = sel4(c, tl[0] - tk[0], s1, s2, s3);
+	uint64_t cum = (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+	uint64_t bb = xb + (xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) + cum;
+	o.x0 = is_back ? lo : bb;
+	o.x1 = is_back ? bb : lo;
+	o.x2 = sz;
+	if (!live) return 0;
+	uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;
+}
+
+// occ4 by ONE lane: the lane reads its own 64-byte block (4 x 16 B, every fetched byte used) and counts alone.
+__device__ __forceinline__ void lane_occ4(const DevIndex &ix, uint64_t p, bool live, uint64_t cnt[4])
+{
+	const bool none = (p == ~0ull);
+	uint64_t pp = p - (p >= ix.primary);
+	uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+	if (live && !none) {
+		const uint4 *b = ix.bwt + (pp >> 7) * 4;
+		v0 = b[0]; v1 = b[1]; v2 = b[2]; v3 = b[3];
+	}
+	const int o = (int)(pp & 127) + 1;
+	const uint32_t packed = count_bases64(v2, o < 64 ? o : 64) + count_bases64(v3, o > 64 ? o - 64 : 0);
+	cnt[0] = ((uint64_t)v0.y << 32 | v0.x) + (packed & 0xff);
+	cnt[1] = ((uint64_t)v0.w << 32 | v0.z) + (packed >> 8 & 0xff);
+	cnt[2] = ((uint64_t)v1.y << 32 | v1.x) + (packed >> 16 & 0xff);
+	cnt[3] = ((uint64_t)v1.w << 32 | v1.z) + (packed >> 24);
+	if (none) cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+}
+// bwt_extend by ONE lane (64 reads per wavefront): 2 x 64 B per lane in flight, no cross-lane traffic at all.
+__device__ __forceinline__ int lane_extend_c(const DevIndex &ix, const Bi &ik, int is_back, int c, bool live, Bi &o)
+{
+	uint64_t xa = is_back ? ik.x0 : ik.x1;
+	uint64_t xb = is_back ? ik.x1 : ik.x0;
+	uint64_t k = xa - 1, l = k + ik.x2;
+	uint64_t tk[4], tl[4];
+	lane_occ4(ix, k, live, tk);
+	lane_occ4(ix, l, live, tl);
+	uint64_t s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+	uint64_t lo = L2_at(ix, c) + 1 + sel4(c, tk[0], tk[1], tk[2], tk[3]);
+	uint64_t sz = sel4(c, tl[0] - tk[0], s1, s2, s3);
+	uint64_t cum = (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+	uint64_t bb = xb + (xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) + cum;
+	o.x0 = is_back ? lo : bb;
+	o.x1 = is_back ? bb : lo;
+	o.x2 = sz;
+	if (!live) return 0;
+	uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;
+}
+
 // One LF step (bwt.c:53 bwt_invPsi) by a quad; k uniform inside the quad; all lanes get the result.
 __device__ __forceinline__ uint64_t quad_lf(const DevIndex &ix, uint64_t k)
 {

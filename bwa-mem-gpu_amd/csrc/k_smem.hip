@@ -22,7 +22,6 @@
 
 namespace {
 
-constexpr int G = 8;
 enum : int { ST_IDLE = 0, ST_NEXT, ST_FWD, ST_BWD, ST_FWD3, ST_FINISH };
 
 __device__ __forceinline__ void put(DevIntv *p, uint64_t x0, uint64_t x1, uint64_t x2, uint64_t info)
@@ -43,6 +42,8 @@ __device__ __forceinline__ void get(const DevIntv *p, uint64_t &x0, uint64_t &x1
 __device__ __forceinline__ uint64_t get_info(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].y; }
 __device__ __forceinline__ uint64_t get_x2(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].x; }
 
+// G = lanes per read: 8 (one quad per Occ block of an extend) or 4 (one quad does both blocks; 16 reads per wavefront)
+template <int G>
 __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 {
 	const int lane = lane_id();
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 		if (st == ST_IDLE && !exhausted) {
 			unsigned t = 0;
 			if (gl == 0) t = atomicAdd(a.queue, 1u);
-			t = __shfl(t, lane & ~(G - 1));
+			if (G > 1) t = __shfl(t, lane & ~(G - 1));
 			if (t >= (unsigned)a.n_reads) exhausted = true;
 			else {
 				rd = (int)t; q = a.seq + a.off[t]; len = (int)(a.off[t + 1] - a.off[t]);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 
 		// ---------------------------------------------------------------- run to the next bwt_extend
 		bool need = false; int is_back = 0, cb = 0; Bi req = { 0, 0, 0 };
-		for (int spin = 0; spin < 8192 && !need && st != ST_IDLE; ++spin) {
+		for (int spin = 0; spin < 8192 && !need && st != ST_IDLE && st != ST_FINISH; ++spin) {
 			if (st == ST_NEXT) {
 				if (pass == 1) {
 					while (x < len && q[x] > 3) ++x;              // bwamem.c:145,154
@@ -153,39 +154,53 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 			} else if (st == ST_FWD3) {
 				if (i < len && q[i] < 4) { need = true; is_back = 0; req = ik; cb = 3 - q[i]; }
 				else { x = i < len ? i + 1 : len; st = ST_NEXT; }   // bwt.c:376-378
-			} else if (st == ST_FINISH) {
-				// sort by info (bwamem.c:184) with a rank sort and write the read's interval list
-				int n = out_n < cap ? out_n : cap, n_seed = 0;
-				DevIntv *dst = a.out + (size_t)rd * cap;
-				for (int t = gl; t < n; t += G) {
+			}
+		}
+
+		// ---------------------------------------------------------------- finished reads: the whole wavefront sorts each one
+		// (bwamem.c:184, by info) with a rank sort over 64 lanes and writes the read's interval list; doing this
+		// inside one lane would stall the other reads of the wavefront for O(n^2) steps
+		uint64_t fm = __ballot(st == ST_FINISH && gl == 0);
+		if (fm) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // U was written by the owner lanes, read by all below
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			while (fm) {
+				const int src = __ffsll((unsigned long long)fm) - 1;
+				fm &= fm - 1;
+				const int s_out = __shfl(out_n, src), s_rd = __shfl(rd, src);
+				const int n = s_out < cap ? s_out : cap;
+				const DevIntv *Us = a.scratch + (size_t)(group - lane / G + src / G) * (2 * (size_t)lcap + cap) + 2 * (size_t)lcap;
+				DevIntv *dst = a.out + (size_t)s_rd * cap;
+				int n_seed = 0;
+				for (int t = lane; t < n; t += 64) {
 					uint64_t x0, x1, x2, info;
-					get(U + t, x0, x1, x2, info);
+					get(Us + t, x0, x1, x2, info);
 					int rank = 0;
 					for (int u = 0; u < n; ++u) {
-						uint64_t ku = get_info(U + u);
+						uint64_t ku = get_info(Us + u);
 						rank += (ku < info) || (ku == info && u < t);
 					}
 					put(dst + rank, x0, x1, x2, info);
-				}
-				for (int t = 0; t < n; ++t) {                   // number of SA look-ups chaining will make (bwamem.c:285-286)
-					uint64_t x2 = get_x2(U + t);
-					uint64_t step = x2 > (uint64_t)a.opt.max_occ ? x2 / a.opt.max_occ : 1;
-					uint64_t cnt = (x2 + step - 1) / step;
+					// number of SA look-ups chaining will make for this interval (bwamem.c:285-286)
+					uint64_t cnt = x2;
+					if (x2 > (uint64_t)a.opt.max_occ) { uint64_t step = x2 / a.opt.max_occ; cnt = (x2 + step - 1) / step; }
 					n_seed += (int)(cnt < (uint64_t)a.opt.max_occ ? cnt : (uint64_t)a.opt.max_occ);
 				}
-				if (gl == 0) {
-					a.out_n[rd] = out_n;                         // > cap tells the host to re-run with more room
-					a.seed_cnt[rd] = out_n > cap ? 0 : n_seed;
+				for (int m = 32; m; m >>= 1) n_seed += __shfl_xor(n_seed, m);
+				if (lane == src) {
+					a.out_n[s_rd] = s_out;                           // > cap tells the host to re-run with more room
+					a.seed_cnt[s_rd] = s_out > cap ? 0 : n_seed;
 					n_out += n;
 				}
-				st = ST_IDLE; rd = -1;
+				if ((lane & ~(G - 1)) == src) { st = ST_IDLE; rd = -1; }
 			}
 		}
 
 		// ---------------------------------------------------------------- the one convergent bwt_extend
 		Bi o;
 		bool live = need && !(st == ST_FWD3 && ik.x2 == 0);     // an empty interval stays empty: no gather needed
-		int nb = group8_extend_c(ix, req, is_back, cb, live, o);
+		int nb = G == 8 ? group8_extend_c(ix, req, is_back, cb, live, o) : G == 4 ? quad_extend_c(ix, req, is_back, cb, live, o)
+		                                                                        : lane_extend_c(ix, req, is_back, cb, live, o);
 		if (need && gl == 0) { ++n_ext; n_blk += nb; }
 
 		// ---------------------------------------------------------------- consume the result
@@ -239,20 +254,22 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 
 } // namespace
 
-int smem_default_groups(int)
+int smem_default_groups(int G)
 {
 	int dev = 0, cus = 256;
 	hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
 	// 8 waves per SIMD x 4 SIMDs = 32 waves (8 workgroups of 256) per CU, 8 groups per wave
-	return cus * 32 * (64 / G);
+	return cus * 32 * (64 / (G == 1 ? 1 : G == 4 ? 4 : 8));
 }
 
-int launch_smem(const SmemLaunch &a, int, hipStream_t st)
+int launch_smem(const SmemLaunch &a, int G, hipStream_t st)
 {
 	int groups = a.groups_total;
-	int blocks = groups / (256 / G);
+	int blocks = groups / (256 / (G == 1 ? 1 : G == 4 ? 4 : 8));
 	if (blocks < 1) blocks = 1;
-	hipLaunchKernelGGL(k_smem, dim3(blocks), dim3(256), 0, st, a);
+	if (G == 1) hipLaunchKernelGGL(k_smem<1>, dim3(blocks), dim3(256), 0, st, a);
+	else if (G == 4) hipLaunchKernelGGL(k_smem<4>, dim3(blocks), dim3(256), 0, st, a);
+	else hipLaunchKernelGGL(k_smem<8>, dim3(blocks), dim3(256), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

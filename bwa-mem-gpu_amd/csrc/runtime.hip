@@ -311,7 +311,8 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	int rc;
 	for (int attempt = 0; attempt < 8; ++attempt) {
 		const int cap = c->intv_cap, lcap = c->max_len + 2;
-		const int groups = smem_default_groups(8);
+		static const int G = getenv("BWAHIP_SMEM_LANES") ? atoi(getenv("BWAHIP_SMEM_LANES")) : 4;   // lanes per read in k_smem (4 or 8)
+		const int groups = smem_default_groups(G);
 		if ((rc = c->d_intv.ensure((size_t)n * cap * sizeof(DevIntv)))) return rc;
 		if ((rc = c->d_intv_n.ensure((size_t)n * 4)) || (rc = c->d_seed_cnt.ensure((size_t)n * 4)) || (rc = c->d_lrep.ensure((size_t)n * 4))) return rc;
 		if ((rc = c->d_seed_base.ensure((size_t)(n + 1) * 8))) return rc;
@@ -324,7 +325,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		sl.seed_cnt = c->d_seed_cnt.as<int>(); sl.l_rep = c->d_lrep.as<int>();
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-		if ((rc = launch_smem(sl, 8, c->stream))) return rc;
+		if ((rc = launch_smem(sl, G, c->stream))) return rc;
 		STAGE_LOG("k_smem");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n);
