@@ -76,6 +76,7 @@ DevOpt make_dev_opt(const bwahip_opt_t *o);
 struct SmemLaunch {
 	DevIndex ix; DevOpt opt;
 	int n_reads; const uint8_t *seq; const int64_t *off;
+	uint64_t *seq4; int seq4_stride;            // reads as 4-bit codes, seq4_stride 64-bit words per read (k_pack4)
 	DevIntv *out; int *out_n; int cap;          // per read: out[read*cap .. ), out_n[read]
 	int *seed_cnt;                              // per read: number of SA look-ups chaining will do (bwamem.c:285-286)
 	float *frac_rep_lrep;                       // unused slot (kept for layout stability)
@@ -87,6 +88,7 @@ struct SmemLaunch {
 	int groups_total;
 };
 int launch_smem(const SmemLaunch &a, int group_lanes, hipStream_t st);
+int launch_pack4(const SmemLaunch &a, hipStream_t st);
 int smem_default_groups(int group_lanes);
 
 struct SeedLaunch {

@@ -14,10 +14,12 @@
 //   pass 3  bwamem.c:167-182   bwt_seed_strategy1 (bwt.c:358): forward-only, stop at occ < max_mem_intv
 //   sort    bwamem.c:184       by info=(qbeg<<32|qend); entries with equal info are the same bi-interval
 //                              (same query substring), so any sort yields the reference's array
-// Lists prev/curr (bwt.c:293) live in a per-group HBM scratch (L2 resident); the per-call `mem`
+// Lists prev/curr (bwt.c:293) are ONE in-place list of 16-byte packed entries per read: curr[k] (k <= j) overwrites
+// the already consumed prev[k], so the swap of bwt.c:340 is a change of (base, n).  Its first 9*G entries live
+// in LDS (the memory system is request-rate bound on this access pattern -- see scripts/gather_bw.hip -- and the
+// list was more than half of all requests); longer lists spill to a per-group HBM area.  The per-call `mem`
 // vector of bwt_smem1a is not materialised: only its last start coordinate is needed (bwt.c:333).
-// Every lane of a group keeps an identical copy of the state and performs the (identical) list
-// stores itself, so each lane only ever re-reads bytes it has written: no cross-lane memory hazard.
+// Every lane of a group keeps an identical copy of the state; lane 0 of the group writes the LDS entries.
 #include "fmi_dev.h"
 
 namespace {
@@ -42,9 +44,48 @@ __device__ __forceinline__ void get(const DevIntv *p, uint64_t &x0, uint64_t &x1
 __device__ __forceinline__ uint64_t get_info(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].y; }
 __device__ __forceinline__ uint64_t get_x2(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].x; }
 
+// list entry = (x0, x1, x2 : 38 bits each, query end : 14 bits); runtime.hip refuses indexes >= 2^38 positions
+__device__ __forceinline__ uint4 pack_entry(uint64_t x0, uint64_t x1, uint64_t x2, uint32_t end)
+{
+	uint64_t lo = x0 | x1 << 38, hi = x1 >> 26 | x2 << 12 | (uint64_t)end << 50;
+	return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ void unpack_entry(uint4 v, uint64_t &x0, uint64_t &x1, uint64_t &x2, uint64_t &end)
+{
+	uint64_t lo = (uint64_t)v.y << 32 | v.x, hi = (uint64_t)v.w << 32 | v.z;
+	const uint64_t M = (1ull << 38) - 1;
+	x0 = lo & M; x1 = (lo >> 38 | hi << 26) & M; x2 = hi >> 12 & M; end = hi >> 50;
+}
+
+// The read as 4-bit codes, 16 bases per 64-bit word (k_pack4 below); positions past the end hold 0xF.  A lane keeps
+// the word it is walking in a register, so the per-step base look-up is a shift and only every 16th step is a load
+// (byte loads of q[i] missed the L1 on nearly every step: the Occ gathers stream through it).
+__device__ __forceinline__ int qbase(const uint64_t *row, int p, uint64_t &qw, int &qwi)
+{
+	const int wi = p >> 4;
+	if (wi != qwi) { qw = row[wi]; qwi = wi; }
+	return (int)(qw >> ((p & 15) * 4)) & 15;
+}
+
+__global__ __launch_bounds__(256) void k_pack4(int n_reads, const uint8_t *seq, const int64_t *off, uint64_t *seq4, int stride)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (int64_t)n_reads * stride) return;
+	const int r = (int)(t / stride), w = (int)(t % stride);
+	const uint8_t *s = seq + off[r];
+	const int len = (int)(off[r + 1] - off[r]);
+	uint64_t v = 0;
+	for (int k = 0; k < 16; ++k) {
+		const int p = w * 16 + k;
+		const uint64_t code = p < len ? (s[p] > 3 ? 4 : s[p]) : 15;
+		v |= code << (4 * k);
+	}
+	seq4[t] = v;
+}
+
 // G = lanes per read: 8 (one quad per Occ block of an extend) or 4 (one quad does both blocks; 16 reads per wavefront)
 template <int G>
-__global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
+__global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 {
 	const int lane = lane_id();
 	const int gl = lane & (G - 1);
@@ -52,25 +93,37 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 	const DevIndex &ix = a.ix;
 	const int min_seed_len = a.opt.min_seed_len, cap = a.cap, lcap = a.lcap;
 
-	DevIntv *const lists = a.scratch + (size_t)group * (2 * (size_t)lcap + cap);
-	DevIntv *const U = lists + 2 * (size_t)lcap;             // unsorted accumulated intervals of the read
+	constexpr int LL = 9 * G;                                // list entries kept in LDS per read
+	__shared__ uint4 lds_list[(256 / G) * (LL + 1)];         // +1: rows start on different banks
+	uint4 *const lrow = lds_list + (threadIdx.x / G) * (LL + 1);
+	DevIntv *const region = a.scratch + (size_t)group * (2 * (size_t)lcap + cap);
+	uint4 *const spill = reinterpret_cast<uint4*>(region);   // list entries LL.. (lcap of them fit twice over)
+	DevIntv *const U = region + 2 * (size_t)lcap;            // unsorted accumulated intervals of the read
 
 	// ---- per-group state (identical in every lane of the group; plain scalars so it stays in registers) ----
 	int st = ST_IDLE, rd = -1, len = 0, pass = 0;
-	const uint8_t *q = nullptr;
+	const uint64_t *qrow = nullptr; uint64_t qw = 0; int qwi = -1;
 	int x = 0, i = 0, j = 0, c = 0, min_intv = 1, ret = 0, p2k = 0, old_n = 0, out_n = 0;
-	int prev_n = 0, curr_n = 0, prev_buf = 0, prev_rev = 0, mem_n = 0, mem_last_start = 0;
+	int prev_n = 0, curr_n = 0, base = 0, mem_n = 0, mem_last_start = 0;
 	uint64_t curr_last_x2 = 0, p_info = 0;
 	Bi ik = { 0, 0, 0 };
 	uint32_t ik_end = 0, last_push_end = 0;
 	int guard = 0;
 	bool exhausted = false;
-	unsigned long long n_ext = 0, n_blk = 0, n_out = 0;
+	unsigned int n_ext = 0, n_blk = 0, n_out = 0;
 
-#define PREV_AT(jj) (lists + (size_t)prev_buf * lcap + (prev_rev ? prev_n - 1 - (jj) : (jj)))
-#define CURR_PUSH(X0, X1, X2, INFO) do { \
-		put(lists + (size_t)(prev_buf ^ 1) * lcap + curr_n, (X0), (X1), (X2), (INFO)); \
-		++curr_n; curr_last_x2 = (X2); } while (0)
+	// physical slot P of the list: LDS below LL, HBM spill above
+#define LIST_PUT(P, X0, X1, X2, END) do { \
+		const int p_ = (P); const uint4 v_ = pack_entry((X0), (X1), (X2), (uint32_t)(END)); \
+		if (p_ < LL) { if (gl == 0) lrow[p_] = v_; } else spill[p_ - LL] = v_; } while (0)
+#define LIST_GET(P, X0, X1, X2, END) do { \
+		const int p_ = (P); uint4 v_; \
+		if (p_ < LL) v_ = lrow[p_]; else v_ = spill[p_ - LL]; \
+		unpack_entry(v_, (X0), (X1), (X2), (END)); } while (0)
+	// backward phase: prev[jj] is read last-pushed-first (bwt.c:321-324 reverses curr) and stays that way in place
+#define PREV_AT(jj) (base + prev_n - 1 - (jj))
+#define FWD_PUSH(X0, X1, X2, END) do { LIST_PUT(curr_n, (X0), (X1), (X2), (END)); ++curr_n; curr_last_x2 = (X2); } while (0)
+#define BWD_PUSH(X0, X1, X2, END) do { LIST_PUT(PREV_AT(curr_n), (X0), (X1), (X2), (END)); ++curr_n; curr_last_x2 = (X2); } while (0)
 	// kv_push(a->mem, ...) of bwamem.c:151,164,174
 #define EMIT(X0, X1, X2, INFO) do { if (out_n < cap) put(U + out_n, (X0), (X1), (X2), (INFO)); ++out_n; } while (0)
 	// a MEM ends at start coordinate START (bwt.c:332-336); only those >= min_seed_len are kept (bwamem.c:150,163)
@@ -79,16 +132,18 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 			++mem_n; mem_last_start = (START); \
 			if ((int)(uint32_t)(FWD_END) - (START) >= min_seed_len) EMIT((X0), (X1), (X2), (uint64_t)(START) << 32 | (uint32_t)(FWD_END)); \
 		} } while (0)
-#define BASE_AT(p) (((p) < 0 || q[(p)] > 3) ? -1 : (int)q[(p)])
+#define QB(p) qbase(qrow, (p), qw, qwi)
+#define BASE_AT(p) (((p) < 0 || QB(p) > 3) ? -1 : QB(p))
 	// bwt.c:289-303: start bwt_smem1a(X_, MI)
 #define START_SMEM(X_, MI) do { \
 		x = (X_); min_intv = (MI) < 1 ? 1 : (MI); \
-		mem_n = 0; curr_n = 0; prev_buf = 0; curr_last_x2 = 0; \
-		set_intv(ix, q[x], ik); ik_end = (uint32_t)(x + 1); i = x + 1; st = ST_FWD; } while (0)
+		mem_n = 0; curr_n = 0; base = 0; curr_last_x2 = 0; \
+		set_intv(ix, QB(x), ik); ik_end = (uint32_t)(x + 1); i = x + 1; st = ST_FWD; } while (0)
 	// bwt.c:321-324: curr reversed becomes prev; its first entry is the last one pushed
 #define FWD_FINISH() do { \
 		ret = (int)last_push_end; \
-		prev_buf ^= 1; prev_n = curr_n; prev_rev = 1; curr_n = 0; \
+		__builtin_amdgcn_wave_barrier(); \
+		prev_n = curr_n; base = 0; curr_n = 0; \
 		i = x - 1; j = 0; c = BASE_AT(i); st = ST_BWD; } while (0)
 	// bwt.c:343 break; pass 1 continues at the forward end (bwamem.c:146)
 #define BWD_FINISH() do { st = ST_NEXT; if (pass == 1) x = ret; } while (0)
@@ -101,7 +156,7 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 			if (G > 1) t = __shfl(t, lane & ~(G - 1));
 			if (t >= (unsigned)a.n_reads) exhausted = true;
 			else {
-				rd = (int)t; q = a.seq + a.off[t]; len = (int)(a.off[t + 1] - a.off[t]);
+				rd = (int)t; qrow = a.seq4 + (size_t)t * a.seq4_stride; qwi = -1; len = (int)(a.off[t + 1] - a.off[t]);
 				out_n = 0; pass = 1; x = 0; guard = 0;
 				st = len < min_seed_len ? ST_FINISH : ST_NEXT;   // bwamem.c:267
 			}
@@ -113,7 +168,7 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 		for (int spin = 0; spin < 8192 && !need && st != ST_IDLE && st != ST_FINISH; ++spin) {
 			if (st == ST_NEXT) {
 				if (pass == 1) {
-					while (x < len && q[x] > 3) ++x;              // bwamem.c:145,154
+					while (x < len && QB(x) > 3) ++x;             // bwamem.c:145,154
 					if (x < len) START_SMEM(x, 1);
 					else { pass = 2; old_n = out_n < cap ? out_n : cap; p2k = 0; }
 				} else if (pass == 2) {
@@ -123,36 +178,36 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 						get(U + p2k, x0, x1, x2, info); ++p2k;
 						int b = (int)(info >> 32), e = (int)(uint32_t)info;
 						if (e - b < a.opt.split_len || x2 > (uint64_t)a.opt.split_width) continue;   // bwamem.c:160
-						if (q[(b + e) >> 1] > 3) continue;        // bwt.c:296 (cannot happen inside an exact match)
+						if (QB((b + e) >> 1) > 3) continue;       // bwt.c:296 (cannot happen inside an exact match)
 						START_SMEM((b + e) >> 1, (int)x2 + 1);
 						started = true;
 					}
 					if (!started) { pass = 3; x = 0; if (a.opt.max_mem_intv <= 0) st = ST_FINISH; }
 				} else {
-					while (x < len && q[x] > 3) ++x;              // bwamem.c:170,181
-					if (x < len) { set_intv(ix, q[x], ik); i = x + 1; st = ST_FWD3; }
+					while (x < len && QB(x) > 3) ++x;             // bwamem.c:170,181
+					if (x < len) { set_intv(ix, QB(x), ik); i = x + 1; st = ST_FWD3; }
 					else st = ST_FINISH;
 				}
 			} else if (st == ST_FWD) {
-				if (i < len && q[i] < 4) { need = true; is_back = 0; req = ik; cb = 3 - q[i]; }
+				if (i < len && QB(i) < 4) { need = true; is_back = 0; req = ik; cb = 3 - QB(i); }
 				else {                                           // end of read / ambiguous base (bwt.c:316-320)
-					CURR_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
+					FWD_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
 					FWD_FINISH();
 				}
 			} else if (st == ST_BWD) {
 				if (c < 0) {                                     // read start or ambiguous base: every prev[] ends here
 					for (int jj = 0; jj < prev_n; ++jj) {
 						uint64_t x0, x1, x2, info;
-						get(PREV_AT(jj), x0, x1, x2, info);
+						LIST_GET(PREV_AT(jj), x0, x1, x2, info);
 						FOUND_MEM(x0, x1, x2, info, i + 1);
 					}
 					BWD_FINISH();
 				} else {
-					get(PREV_AT(j), req.x0, req.x1, req.x2, p_info);
+					LIST_GET(PREV_AT(j), req.x0, req.x1, req.x2, p_info);
 					need = true; is_back = 1; cb = c;
 				}
 			} else if (st == ST_FWD3) {
-				if (i < len && q[i] < 4) { need = true; is_back = 0; req = ik; cb = 3 - q[i]; }
+				if (i < len && QB(i) < 4) { need = true; is_back = 0; req = ik; cb = 3 - QB(i); }
 				else { x = i < len ? i + 1 : len; st = ST_NEXT; }   // bwt.c:376-378
 			}
 		}
@@ -211,7 +266,7 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 			} else if (st == ST_FWD) {                             // bwt.c:308-315
 				bool stop = false;
 				if (o.x2 != ik.x2) {
-					CURR_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
+					FWD_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
 					if (o.x2 < (uint64_t)min_intv) stop = true;
 				}
 				if (stop) FWD_FINISH();
@@ -220,12 +275,13 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 				if (o.x2 < (uint64_t)min_intv) {
 					if (curr_n == 0) FOUND_MEM(req.x0, req.x1, req.x2, p_info, i + 1);
 				} else if (curr_n == 0 || o.x2 != curr_last_x2) {
-					CURR_PUSH(o.x0, o.x1, o.x2, p_info);
+					BWD_PUSH(o.x0, o.x1, o.x2, p_info);
 				}
 				if (++j == prev_n) {
 					if (curr_n == 0) BWD_FINISH();
 					else {
-						prev_buf ^= 1; prev_n = curr_n; prev_rev = 0; curr_n = 0;
+						__builtin_amdgcn_wave_barrier();
+						base += prev_n - curr_n; prev_n = curr_n; curr_n = 0;   // bwt.c:340 swap, in place
 						--i; j = 0; c = BASE_AT(i);
 					}
 				}
@@ -238,15 +294,19 @@ __global__ __launch_bounds__(256) void k_smem(SmemLaunch a)
 		}
 	}
 	if (gl == 0 && (n_ext | n_out)) {
-		atomicAdd(&a.counters[CNT_EXTEND], n_ext);
-		atomicAdd(&a.counters[CNT_BLOCKS], n_blk);
-		atomicAdd(&a.counters[CNT_INTV], n_out);
+		atomicAdd(&a.counters[CNT_EXTEND], (unsigned long long)n_ext);
+		atomicAdd(&a.counters[CNT_BLOCKS], (unsigned long long)n_blk);
+		atomicAdd(&a.counters[CNT_INTV], (unsigned long long)n_out);
 	}
 #undef PREV_AT
-#undef CURR_PUSH
+#undef FWD_PUSH
+#undef BWD_PUSH
+#undef LIST_PUT
+#undef LIST_GET
 #undef EMIT
 #undef FOUND_MEM
 #undef BASE_AT
+#undef QB
 #undef START_SMEM
 #undef FWD_FINISH
 #undef BWD_FINISH
@@ -261,6 +321,13 @@ int smem_default_groups(int G)
 	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
 	// 8 waves per SIMD x 4 SIMDs = 32 waves (8 workgroups of 256) per CU, 8 groups per wave
 	return cus * 32 * (64 / (G == 1 ? 1 : G == 4 ? 4 : 8));
+}
+
+int launch_pack4(const SmemLaunch &a, hipStream_t st)
+{
+	const int64_t words = (int64_t)a.n_reads * a.seq4_stride;
+	hipLaunchKernelGGL(k_pack4, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, a.n_reads, a.seq, a.off, a.seq4, a.seq4_stride);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
 int launch_smem(const SmemLaunch &a, int G, hipStream_t st)

@@ -57,7 +57,7 @@ struct bwahip_ctx {
 	// batch state
 	int n_reads = 0, max_len = 0;
 	int64_t total_bases = 0;
-	DevBuf d_seq, d_off;
+	DevBuf d_seq, d_off, d_seq4;
 	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
 	DevBuf d_misc;                       // [0..15] counters (u64), then queue (u32), err (i32)
 	// K3/K4 working set (sized from the seed count of the batch)
@@ -212,7 +212,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
@@ -305,6 +305,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	const int n = c->n_reads;
 	if (n == 0) return 0;
 	DevOpt dopt = make_dev_opt(opt);
+	if (c->ix.seq_len >= (1ull << 38) || c->max_len >= (1 << 14)) return BWAHIP_EINVAL;   // k_smem packs list entries as 3 x 38 + 14 bits
 	unsigned long long *counters = c->d_misc.as<unsigned long long>();
 	unsigned int *queue = (unsigned int*)(counters + CNT_N);
 	int *err = (int*)(queue + 4);
@@ -323,6 +324,10 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		sl.ix = c->ix; sl.opt = dopt; sl.n_reads = n; sl.seq = c->d_seq.as<uint8_t>(); sl.off = c->d_off.as<int64_t>();
 		sl.out = c->d_intv.as<DevIntv>(); sl.out_n = c->d_intv_n.as<int>(); sl.cap = cap;
 		sl.seed_cnt = c->d_seed_cnt.as<int>(); sl.l_rep = c->d_lrep.as<int>();
+		sl.seq4_stride = (c->max_len + 15) / 16 + 1;            // +1: a word of 0xF past the longest read
+		if ((rc = c->d_seq4.ensure((size_t)n * sl.seq4_stride * 8))) return rc;
+		sl.seq4 = c->d_seq4.as<uint64_t>();
+		if (attempt == 0 && (rc = launch_pack4(sl, c->stream))) return rc;
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
 		if ((rc = launch_smem(sl, G, c->stream))) return rc;
