@@ -127,7 +127,8 @@ def main():
         k1 = float(np.mean([k["k_smem"] for k in kms]))
         # algorithmic bytes of the BWT-search kernel per launch: 64 B per Occ block touched by
         # bwt_extend + the read bytes in + 32 B per interval out, counted by the kernel itself
-        alg_bytes = 64 * counters["blocks"] + args.reads * args.read_len + 32 * counters["intv"]
+        # (the few reads k_smem hands to k_smem_heavy are counted by that kernel and subtracted here)
+        alg_bytes = 64 * (counters["blocks"] - counters["heavy_blocks"]) + args.reads * args.read_len + 32 * (counters["intv"] - counters["heavy_intv"])
         achieved = alg_bytes / (k1 * 1e-3) / 1e9
         out = {
             "metric": "reads/s aligned (150 bp vs hg38-scale synthetic genome), hot path mem_align1_core on GPU",
@@ -146,7 +147,7 @@ def main():
                          "sa_lookups": round(counters["sa"] / args.reads, 2), "lf_steps": round(counters["lf"] / args.reads, 1),
                          "dp_cells": round(counters["cells"] / args.reads, 1)},
             "tail_us": {k: round(v / 100.0, 1) for k, v in counters.items() if k.endswith("_max")},
-            "tail_counts": {"max_seeds_per_read": counters.get("max_seeds"), "max_chains_per_read": counters.get("max_chains")},
+            "tail_counts": {"max_extends_per_read": counters.get("max_extends"), "max_seeds_per_read": counters.get("max_seeds"), "max_chains_per_read": counters.get("max_chains")},
             "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k1, 3)},

@@ -241,10 +241,11 @@ class Context:
         return {lib().bwahip_kernel_name(i).decode(): float(ms[i]) for i in range(nk)}
 
     def counters(self):
-        buf = (C.c_uint64 * 16)()
-        _check(lib().bwahip_batch_counters(self._h, buf, 16), "bwahip_batch_counters")
-        names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells", "_7", "chain_build_max", "chain_sort_max", "chain_flt_max",
-                 "chain_write_max", "max_seeds", "max_chains", "ext_max", "ext_dedup_max"]
+        buf = (C.c_uint64 * 24)()
+        _check(lib().bwahip_batch_counters(self._h, buf, 24), "bwahip_batch_counters")
+        names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells", "max_extends", "chain_build_max", "chain_sort_max", "chain_flt_max",
+                 "chain_write_max", "max_seeds", "max_chains", "ext_max", "ext_dedup_max", "heavy_blocks", "heavy_intv", "heavy_reads",
+                 "_19", "_20", "_21", "_22", "_23"]
         return {k: int(buf[i]) for i, k in enumerate(names)}
 
     def kat_occ4(self, k):

@@ -37,7 +37,8 @@ struct DevOpt {
 };
 
 // Work counters kept in HBM, bumped once per wavefront at kernel exit (bwahip_batch_counters).
-enum { CNT_EXTEND = 0, CNT_BLOCKS, CNT_SA, CNT_LF, CNT_INTV, CNT_SEEDS, CNT_CELLS, CNT_N = 16 };
+enum { CNT_EXTEND = 0, CNT_BLOCKS, CNT_SA, CNT_LF, CNT_INTV, CNT_SEEDS, CNT_CELLS, CNT_MAX_EXT /* most bwt_extend calls of one read */,
+       CNT_HEAVY_BLOCKS = 16, CNT_HEAVY_INTV, CNT_HEAVY_READS, CNT_N = 24 };
 
 // One interval / list entry in HBM: x[0], x[1], x[2], info  (bwtintv_t, bwt.h:62)
 struct __attribute__((aligned(32))) DevIntv { uint64_t x0, x1, x2, info; };
@@ -80,15 +81,17 @@ struct SmemLaunch {
 	DevIntv *out; int *out_n; int cap;          // per read: out[read*cap .. ), out_n[read]
 	int *seed_cnt;                              // per read: number of SA look-ups chaining will do (bwamem.c:285-286)
 	float *frac_rep_lrep;                       // unused slot (kept for layout stability)
-	int *l_rep;                                 // per read: l_rep of bwamem.c:272-279
-	DevIntv *scratch; int lcap;                 // per group: 2*lcap list entries + cap unsorted intervals
+	int *l_rep;                                 // per read: number of bwt_extend calls (diagnostic)
+	DevIntv *scratch; int lcap;                 // per group: lcap 16-byte list spill entries + cap unsorted intervals
 	unsigned int *queue;                        // work-queue head
 	unsigned long long *counters;
 	int *err;
 	int groups_total;
+	int *heavy_list; unsigned int *heavy_n; int heavy_mult;   // reads handed to k_smem_heavy after heavy_mult*len extends (0: never)
 };
 int launch_smem(const SmemLaunch &a, int group_lanes, hipStream_t st);
 int launch_pack4(const SmemLaunch &a, hipStream_t st);
+int launch_smem_heavy(const SmemLaunch &a, hipStream_t st);
 int smem_default_groups(int group_lanes);
 
 struct SeedLaunch {

@@ -210,6 +210,33 @@ __device__ __forceinline__ int lane_extend_c(const DevIndex &ix, const Bi &ik, i
 	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;
 }
 
+// bwt_extend by a PAIR of lanes (32 reads per wavefront): lane 0 of the pair reads and counts the whole block of k,
+// lane 1 the block of l; one DPP exchange hands each the other's four counts.
+__device__ __forceinline__ uint64_t pair_swap64(uint64_t v) { return (uint64_t)quad_xor1((uint32_t)v) | (uint64_t)quad_xor1((uint32_t)(v >> 32)) << 32; }
+__device__ __forceinline__ int pair_extend_c(const DevIndex &ix, const Bi &ik, int is_back, int c, bool live, Bi &o)
+{
+	const int h = lane_id() & 1;
+	uint64_t xa = is_back ? ik.x0 : ik.x1;
+	uint64_t xb = is_back ? ik.x1 : ik.x0;
+	uint64_t k = xa - 1, l = k + ik.x2;
+	uint64_t mine[4];
+	lane_occ4(ix, h ? l : k, live, mine);
+	uint64_t o0 = pair_swap64(mine[0]), o1 = pair_swap64(mine[1]), o2 = pair_swap64(mine[2]), o3 = pair_swap64(mine[3]);
+	uint64_t tk0 = h ? o0 : mine[0], tk1 = h ? o1 : mine[1], tk2 = h ? o2 : mine[2], tk3 = h ? o3 : mine[3];
+	uint64_t tl0 = h ? mine[0] : o0, tl1 = h ? mine[1] : o1, tl2 = h ? mine[2] : o2, tl3 = h ? mine[3] : o3;
+	uint64_t s1 = tl1 - tk1, s2 = tl2 - tk2, s3 = tl3 - tk3;
+	uint64_t lo = L2_at(ix, c) + 1 + sel4(c, tk0, tk1, tk2, tk3);
+	uint64_t sz = sel4(c, tl0 - tk0, s1, s2, s3);
+	uint64_t cum = (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+	uint64_t bb = xb + (xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) + cum;
+	o.x0 = is_back ? lo : bb;
+	o.x1 = is_back ? bb : lo;
+	o.x2 = sz;
+	if (!live) return 0;
+	uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	return (k == ~0ull || (kk >> 7) != (ll >> 7)) ? 2 : 1;
+}
+
 // One LF step (bwt.c:53 bwt_invPsi) by a quad; k uniform inside the quad; all lanes get the result.
 __device__ __forceinline__ uint64_t quad_lf(const DevIndex &ix, uint64_t k)
 {

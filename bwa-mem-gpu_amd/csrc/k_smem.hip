@@ -83,6 +83,37 @@ __global__ __launch_bounds__(256) void k_pack4(int n_reads, const uint8_t *seq, 
 	seq4[t] = v;
 }
 
+// Finish one read with the whole wavefront: sort its n_emit unsorted intervals U by info (bwamem.c:184; entries with equal
+// info are identical, so a rank sort gives the reference's array), write the list, its length and the number of SA
+// look-ups chaining will make (bwamem.c:285-286).  All arguments are wavefront-uniform.  Returns the number written.
+__device__ __forceinline__ int wave_finish_read(const SmemLaunch &a, const DevIntv *Us, int n_emit, int rd, int n_ext, int lane)
+{
+	const int cap = a.cap, n = n_emit < cap ? n_emit : cap;
+	DevIntv *dst = a.out + (size_t)rd * cap;
+	int n_seed = 0;
+	for (int t = lane; t < n; t += 64) {
+		uint64_t x0, x1, x2, info;
+		get(Us + t, x0, x1, x2, info);
+		int rank = 0;
+		for (int u = 0; u < n; ++u) {
+			uint64_t ku = get_info(Us + u);
+			rank += (ku < info) || (ku == info && u < t);
+		}
+		put(dst + rank, x0, x1, x2, info);
+		uint64_t cnt = x2;
+		if (x2 > (uint64_t)a.opt.max_occ) { uint64_t step = x2 / a.opt.max_occ; cnt = (x2 + step - 1) / step; }
+		n_seed += (int)(cnt < (uint64_t)a.opt.max_occ ? cnt : (uint64_t)a.opt.max_occ);
+	}
+	for (int m = 32; m; m >>= 1) n_seed += __shfl_xor(n_seed, m);
+	if (lane == 0) {
+		a.out_n[rd] = n_emit;                                // > cap tells the host to re-run with more room
+		a.l_rep[rd] = n_ext;                                 // diagnostic: bwt_extend calls this read needed
+		a.seed_cnt[rd] = n_emit > cap ? 0 : n_seed;
+		if ((unsigned long long)n_ext > a.counters[CNT_MAX_EXT]) atomicMax(&a.counters[CNT_MAX_EXT], (unsigned long long)n_ext);
+	}
+	return n;
+}
+
 // G = lanes per read: 8 (one quad per Occ block of an extend) or 4 (one quad does both blocks; 16 reads per wavefront)
 template <int G>
 __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
@@ -96,9 +127,10 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 	constexpr int LL = 9 * G;                                // list entries kept in LDS per read
 	__shared__ uint4 lds_list[(256 / G) * (LL + 1)];         // +1: rows start on different banks
 	uint4 *const lrow = lds_list + (threadIdx.x / G) * (LL + 1);
-	DevIntv *const region = a.scratch + (size_t)group * (2 * (size_t)lcap + cap);
-	uint4 *const spill = reinterpret_cast<uint4*>(region);   // list entries LL.. (lcap of them fit twice over)
-	DevIntv *const U = region + 2 * (size_t)lcap;            // unsorted accumulated intervals of the read
+	const size_t region_bytes = (size_t)lcap * 16 + (size_t)cap * 32;
+	char *const region = reinterpret_cast<char*>(a.scratch) + (size_t)group * region_bytes;
+	uint4 *const spill = reinterpret_cast<uint4*>(region);   // list entries LL.. (lcap of them)
+	DevIntv *const U = reinterpret_cast<DevIntv*>(region + (size_t)lcap * 16);   // unsorted accumulated intervals of the read
 
 	// ---- per-group state (identical in every lane of the group; plain scalars so it stays in registers) ----
 	int st = ST_IDLE, rd = -1, len = 0, pass = 0;
@@ -222,31 +254,11 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 			while (fm) {
 				const int src = __ffsll((unsigned long long)fm) - 1;
 				fm &= fm - 1;
-				const int s_out = __shfl(out_n, src), s_rd = __shfl(rd, src);
-				const int n = s_out < cap ? s_out : cap;
-				const DevIntv *Us = a.scratch + (size_t)(group - lane / G + src / G) * (2 * (size_t)lcap + cap) + 2 * (size_t)lcap;
-				DevIntv *dst = a.out + (size_t)s_rd * cap;
-				int n_seed = 0;
-				for (int t = lane; t < n; t += 64) {
-					uint64_t x0, x1, x2, info;
-					get(Us + t, x0, x1, x2, info);
-					int rank = 0;
-					for (int u = 0; u < n; ++u) {
-						uint64_t ku = get_info(Us + u);
-						rank += (ku < info) || (ku == info && u < t);
-					}
-					put(dst + rank, x0, x1, x2, info);
-					// number of SA look-ups chaining will make for this interval (bwamem.c:285-286)
-					uint64_t cnt = x2;
-					if (x2 > (uint64_t)a.opt.max_occ) { uint64_t step = x2 / a.opt.max_occ; cnt = (x2 + step - 1) / step; }
-					n_seed += (int)(cnt < (uint64_t)a.opt.max_occ ? cnt : (uint64_t)a.opt.max_occ);
-				}
-				for (int m = 32; m; m >>= 1) n_seed += __shfl_xor(n_seed, m);
-				if (lane == src) {
-					a.out_n[s_rd] = s_out;                           // > cap tells the host to re-run with more room
-					a.seed_cnt[s_rd] = s_out > cap ? 0 : n_seed;
-					n_out += n;
-				}
+				const int s_out = __shfl(out_n, src), s_rd = __shfl(rd, src), s_ext = __shfl(guard, src);
+				const DevIntv *Us = reinterpret_cast<const DevIntv*>(reinterpret_cast<const char*>(a.scratch) +
+				                                                     (size_t)(group - lane / G + src / G) * region_bytes + (size_t)lcap * 16);
+				const int n = wave_finish_read(a, Us, s_out, s_rd, s_ext, lane);
+				if (lane == src) n_out += n;
 				if ((lane & ~(G - 1)) == src) { st = ST_IDLE; rd = -1; }
 			}
 		}
@@ -254,15 +266,22 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 		// ---------------------------------------------------------------- the one convergent bwt_extend
 		Bi o;
 		bool live = need && !(st == ST_FWD3 && ik.x2 == 0);     // an empty interval stays empty: no gather needed
-		int nb = G == 8 ? group8_extend_c(ix, req, is_back, cb, live, o) : G == 4 ? quad_extend_c(ix, req, is_back, cb, live, o)
+		int nb = G == 8 ? group8_extend_c(ix, req, is_back, cb, live, o) : G == 4 ? quad_extend_c(ix, req, is_back, cb, live, o) : G == 2 ? pair_extend_c(ix, req, is_back, cb, live, o)
 		                                                                        : lane_extend_c(ix, req, is_back, cb, live, o);
 		if (need && gl == 0) { ++n_ext; n_blk += nb; }
 
 		// ---------------------------------------------------------------- consume the result
 		if (need) {
-			if (++guard > 64 * BWAHIP_MAX_READ_LEN) {              // cannot happen; guarantees the grid drains
-				if (gl == 0) atomicExch(a.err, 1);
-				out_n = 0; st = ST_FINISH;
+			if (++guard > (a.heavy_mult > 0 ? a.heavy_mult * len + 64 : 64 * BWAHIP_MAX_READ_LEN)) {
+				// a read deep inside a repeat: thousands of dependent steps would make it the critical path of the whole
+				// launch, so it is handed to k_smem_heavy, which runs each backward step across a wavefront
+				if (a.heavy_mult > 0) {
+					if (gl == 0) { unsigned h = atomicAdd(a.heavy_n, 1u); a.heavy_list[h] = rd; }
+					st = ST_IDLE; rd = -1;
+				} else {                                             // cannot happen; guarantees the grid drains
+					if (gl == 0) atomicExch(a.err, 1);
+					out_n = 0; st = ST_FINISH;
+				}
 			} else if (st == ST_FWD) {                             // bwt.c:308-315
 				bool stop = false;
 				if (o.x2 != ik.x2) {
@@ -312,6 +331,181 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 #undef BWD_FINISH
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K1b -- the reads k_smem gave up on (more than heavy_mult x len bwt_extend calls: reads inside large repeat families).
+// One read per wavefront.  The forward extension of bwt_smem1a is inherently serial and runs wavefront-uniform; the
+// backward sweep (bwt.c:326-345) extends every entry of prev[] by the same base, which is independent work: lane j takes
+// prev[j] and the order-dependent parts are resolved with ballots --
+//   * kv_push(curr) happens iff the candidate differs in x[2] from the previous *candidate* (pushed or not: a skipped
+//     candidate has the x[2] of the last pushed one), so the test is local to neighbouring candidates;
+//   * a MEM is recorded only while curr is empty and only once per sweep step (the second attempt fails
+//     i+1 < mem.last.start), i.e. only for j == 0.
+// The list lives in LDS (in place, as in k_smem).
+struct HeavyRead {
+	const uint64_t *qrow; int len;
+	uint4 *L; DevIntv *U;
+	int out_n, ext;
+	uint64_t qw; int qwi;
+	unsigned n_ext, n_blk;                                   // per-lane work counters
+};
+
+__device__ __forceinline__ void heavy_emit(const SmemLaunch &a, HeavyRead &r, int lane, uint64_t x0, uint64_t x1, uint64_t x2, uint64_t info)
+{
+	if (r.out_n < a.cap && lane == 0) put(r.U + r.out_n, x0, x1, x2, info);
+	++r.out_n;
+}
+
+// bwt_smem1a(x, min_intv) (bwt.c:285-347); returns the forward end (ret)
+__device__ __forceinline__ int heavy_smem1(const SmemLaunch &a, HeavyRead &r, int lane, int x, int min_intv)
+{
+	const DevIndex &ix = a.ix;
+	const int len = r.len, min_seed_len = a.opt.min_seed_len;
+	if (min_intv < 1) min_intv = 1;
+	Bi ik; set_intv(ix, qbase(r.qrow, x, r.qw, r.qwi), ik);
+	uint32_t ik_end = (uint32_t)(x + 1), last_end = 0;
+	int n = 0, i;
+	for (i = x + 1; i < len; ++i) {                          // forward: wavefront-uniform (bwt.c:304-320)
+		const int b = qbase(r.qrow, i, r.qw, r.qwi);
+		if (b < 4) {
+			Bi o;
+			int nb = lane_extend_c(ix, ik, 0, 3 - b, true, o);
+			if (lane == 0) { ++r.n_ext; r.n_blk += nb; }
+			++r.ext;
+			if (o.x2 != ik.x2) {
+				if (lane == 0) r.L[n] = pack_entry(ik.x0, ik.x1, ik.x2, ik_end);
+				++n; last_end = ik_end;
+				if (o.x2 < (uint64_t)min_intv) break;
+			}
+			ik = o; ik_end = (uint32_t)(i + 1);
+		} else {
+			if (lane == 0) r.L[n] = pack_entry(ik.x0, ik.x1, ik.x2, ik_end);
+			++n; last_end = ik_end;
+			break;
+		}
+	}
+	if (i == len) { if (lane == 0) r.L[n] = pack_entry(ik.x0, ik.x1, ik.x2, ik_end); ++n; last_end = ik_end; }
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+	int prev_n = n, base = 0, mem_n = 0, mem_last_start = 0;  // prev[j] = L[base + prev_n - 1 - j]
+	const uint64_t lt = (1ull << lane) - 1;
+	for (i = x - 1; i >= -1; --i) {                          // backward (bwt.c:326-345)
+		int c = -1;
+		if (i >= 0) { const int b = qbase(r.qrow, i, r.qw, r.qwi); if (b < 4) c = b; }
+		uint64_t e0 = 0, e1 = 0, e2 = 0, eend = 0;
+		if (c < 0) {                                         // every prev[] ends here; only prev[0] can be recorded
+			unpack_entry(r.L[base + prev_n - 1], e0, e1, e2, eend);
+			if (mem_n == 0 || i + 1 < mem_last_start) {
+				++mem_n; mem_last_start = i + 1;
+				if ((int)(uint32_t)eend - (i + 1) >= min_seed_len) heavy_emit(a, r, lane, e0, e1, e2, (uint64_t)(i + 1) << 32 | (uint32_t)eend);
+			}
+			break;
+		}
+		int curr_n = 0; bool carry_has = false; uint64_t carry_x2 = 0;
+		for (int chunk = 0; chunk < prev_n; chunk += 64) {
+			const int j = chunk + lane;
+			const bool valid = j < prev_n;
+			e0 = e1 = e2 = eend = 0;
+			if (valid) unpack_entry(r.L[base + prev_n - 1 - j], e0, e1, e2, eend);
+			Bi req = { e0, e1, e2 }, o;
+			int nb = lane_extend_c(ix, req, 1, c, valid, o);
+			if (valid) { ++r.n_ext; r.n_blk += nb; }
+			r.ext += prev_n - chunk < 64 ? prev_n - chunk : 64;
+			const bool isC = valid && o.x2 >= (uint64_t)min_intv;
+			const uint64_t cm = __ballot(isC);
+			if (chunk == 0 && !(cm & 1)) {                   // prev[0] cannot be extended and curr is still empty
+				const uint64_t m0 = __shfl(e0, 0), m1 = __shfl(e1, 0), m2 = __shfl(e2, 0), mend = __shfl(eend, 0);
+				if (mem_n == 0 || i + 1 < mem_last_start) {
+					++mem_n; mem_last_start = i + 1;
+					if ((int)(uint32_t)mend - (i + 1) >= min_seed_len) heavy_emit(a, r, lane, m0, m1, m2, (uint64_t)(i + 1) << 32 | (uint32_t)mend);
+				}
+			}
+			const uint64_t below = cm & lt;
+			const uint64_t nx2 = __shfl(o.x2, below ? 63 - __clzll((long long)below) : 0);
+			const bool phas = below ? true : carry_has;
+			const uint64_t px2 = below ? nx2 : carry_x2;
+			const bool push = isC && (!phas || o.x2 != px2);
+			const uint64_t pm = __ballot(push);
+			const int pos = curr_n + __popcll(pm & lt);
+			__builtin_amdgcn_wave_barrier();                 // every lane has its prev[] entry before slots are reused
+			if (push) r.L[base + prev_n - 1 - pos] = pack_entry(o.x0, o.x1, o.x2, (uint32_t)eend);
+			curr_n += __popcll(pm);
+			if (cm) { carry_has = true; carry_x2 = __shfl(o.x2, 63 - __clzll((long long)cm)); }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (curr_n == 0) break;
+		base += prev_n - curr_n; prev_n = curr_n;            // bwt.c:340 swap, in place
+	}
+	return (int)last_end;
+}
+
+__global__ __launch_bounds__(256) void k_smem_heavy(SmemLaunch a)
+{
+	__shared__ uint4 lists[4][BWAHIP_MAX_READ_LEN + 8];
+	const int lane = lane_id();
+	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+	const DevIndex &ix = a.ix;
+	const size_t region_bytes = (size_t)a.lcap * 16 + (size_t)a.cap * 32;
+	HeavyRead r;
+	r.L = lists[threadIdx.x >> 6];
+	r.U = reinterpret_cast<DevIntv*>(reinterpret_cast<char*>(a.scratch) + (size_t)wave * region_bytes + (size_t)a.lcap * 16);
+	r.n_ext = r.n_blk = 0;
+	const unsigned n_heavy = *a.heavy_n;
+	unsigned n_out = 0;
+	for (unsigned h = (unsigned)wave; h < n_heavy; h += (unsigned)n_waves) {
+		const int rd = a.heavy_list[h];
+		r.qrow = a.seq4 + (size_t)rd * a.seq4_stride; r.qwi = -1; r.qw = 0;
+		r.len = (int)(a.off[rd + 1] - a.off[rd]);
+		r.out_n = 0; r.ext = 0;
+		const int len = r.len;
+		if (len >= a.opt.min_seed_len) {                     // bwamem.c:267
+			for (int x = 0; x < len;) {                      // pass 1 (bwamem.c:144-154)
+				if (qbase(r.qrow, x, r.qw, r.qwi) < 4) x = heavy_smem1(a, r, lane, x, 1);
+				else ++x;
+			}
+			const int old_n = r.out_n < a.cap ? r.out_n : a.cap;   // pass 2 (bwamem.c:156-165)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			for (int k = 0; k < old_n; ++k) {
+				uint64_t x0, x1, x2, info;
+				get(r.U + k, x0, x1, x2, info);
+				const int b = (int)(info >> 32), e = (int)(uint32_t)info;
+				if (e - b < a.opt.split_len || x2 > (uint64_t)a.opt.split_width) continue;
+				if (qbase(r.qrow, (b + e) >> 1, r.qw, r.qwi) > 3) continue;
+				heavy_smem1(a, r, lane, (b + e) >> 1, (int)x2 + 1);
+			}
+			if (a.opt.max_mem_intv > 0) {                    // pass 3 (bwamem.c:167-182, bwt.c:358-380)
+				for (int x = 0; x < len;) {
+					if (qbase(r.qrow, x, r.qw, r.qwi) > 3) { ++x; continue; }
+					Bi ik; set_intv(ix, qbase(r.qrow, x, r.qw, r.qwi), ik);
+					int i, nx = len;
+					for (i = x + 1; i < len; ++i) {
+						const int b = qbase(r.qrow, i, r.qw, r.qwi);
+						if (b > 3) { nx = i + 1; break; }
+						Bi o;
+						const bool live = ik.x2 != 0;
+						int nb = lane_extend_c(ix, ik, 0, 3 - b, live, o);
+						if (lane == 0) { ++r.n_ext; r.n_blk += nb; }
+						++r.ext;
+						if (o.x2 < (uint64_t)a.opt.max_mem_intv && i - x >= a.opt.min_seed_len) {
+							if (o.x2 > 0) heavy_emit(a, r, lane, o.x0, o.x1, o.x2, (uint64_t)x << 32 | (uint32_t)(i + 1));
+							nx = i + 1; break;
+						}
+						ik = o;
+					}
+					x = nx;
+				}
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		n_out += wave_finish_read(a, r.U, r.out_n, rd, r.ext, lane);
+	}
+	unsigned long long e = r.n_ext, b = r.n_blk;
+	for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); }
+	if (lane == 0 && (e | n_out)) {
+		atomicAdd(&a.counters[CNT_EXTEND], e); atomicAdd(&a.counters[CNT_BLOCKS], b); atomicAdd(&a.counters[CNT_INTV], (unsigned long long)n_out);
+		atomicAdd(&a.counters[CNT_HEAVY_BLOCKS], b); atomicAdd(&a.counters[CNT_HEAVY_INTV], (unsigned long long)n_out);
+	}
+}
+
 } // namespace
 
 int smem_default_groups(int G)
@@ -320,7 +514,7 @@ int smem_default_groups(int G)
 	hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
 	// 8 waves per SIMD x 4 SIMDs = 32 waves (8 workgroups of 256) per CU, 8 groups per wave
-	return cus * 32 * (64 / (G == 1 ? 1 : G == 4 ? 4 : 8));
+	return cus * 16 * (64 / (G == 1 || G == 2 || G == 4 ? G : 8));   // 4 waves per SIMD are resident (VGPRs)
 }
 
 int launch_pack4(const SmemLaunch &a, hipStream_t st)
@@ -330,12 +524,21 @@ int launch_pack4(const SmemLaunch &a, hipStream_t st)
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
+int launch_smem_heavy(const SmemLaunch &a, hipStream_t st)
+{
+	int waves = a.groups_total < 4096 ? a.groups_total : 4096;   // one scratch region per wavefront
+	if (waves < 4) return BWAHIP_EINVAL;
+	hipLaunchKernelGGL(k_smem_heavy, dim3(waves / 4), dim3(256), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
 int launch_smem(const SmemLaunch &a, int G, hipStream_t st)
 {
 	int groups = a.groups_total;
-	int blocks = groups / (256 / (G == 1 ? 1 : G == 4 ? 4 : 8));
+	int blocks = groups / (256 / (G == 1 || G == 2 || G == 4 ? G : 8));
 	if (blocks < 1) blocks = 1;
 	if (G == 1) hipLaunchKernelGGL(k_smem<1>, dim3(blocks), dim3(256), 0, st, a);
+	else if (G == 2) hipLaunchKernelGGL(k_smem<2>, dim3(blocks), dim3(256), 0, st, a);
 	else if (G == 4) hipLaunchKernelGGL(k_smem<4>, dim3(blocks), dim3(256), 0, st, a);
 	else hipLaunchKernelGGL(k_smem<8>, dim3(blocks), dim3(256), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, int64_t *out, int 
 }
 } // namespace
 
-static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend" };
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy" };
 
 struct bwahip_ctx {
 	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
@@ -57,7 +57,7 @@ struct bwahip_ctx {
 	// batch state
 	int n_reads = 0, max_len = 0;
 	int64_t total_bases = 0;
-	DevBuf d_seq, d_off, d_seq4;
+	DevBuf d_seq, d_off, d_seq4, d_smem_heavy;
 	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
 	DevBuf d_misc;                       // [0..15] counters (u64), then queue (u32), err (i32)
 	// K3/K4 working set (sized from the seed count of the batch)
@@ -212,7 +212,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
@@ -312,12 +312,12 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	int rc;
 	for (int attempt = 0; attempt < 8; ++attempt) {
 		const int cap = c->intv_cap, lcap = c->max_len + 2;
-		static const int G = getenv("BWAHIP_SMEM_LANES") ? atoi(getenv("BWAHIP_SMEM_LANES")) : 4;   // lanes per read in k_smem (4 or 8)
+		const int G = getenv("BWAHIP_SMEM_LANES") ? atoi(getenv("BWAHIP_SMEM_LANES")) : 1;   // lanes per read in k_smem (1, 2, 4 or 8)
 		const int groups = smem_default_groups(G);
 		if ((rc = c->d_intv.ensure((size_t)n * cap * sizeof(DevIntv)))) return rc;
 		if ((rc = c->d_intv_n.ensure((size_t)n * 4)) || (rc = c->d_seed_cnt.ensure((size_t)n * 4)) || (rc = c->d_lrep.ensure((size_t)n * 4))) return rc;
 		if ((rc = c->d_seed_base.ensure((size_t)(n + 1) * 8))) return rc;
-		if ((rc = c->d_scratch.ensure((size_t)groups * (2 * (size_t)lcap + cap) * sizeof(DevIntv)))) return rc;
+		if ((rc = c->d_scratch.ensure((size_t)groups * ((size_t)lcap * 16 + (size_t)cap * 32)))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 1024, c->stream));
 		SmemLaunch sl;
 		memset(&sl, 0, sizeof sl);
@@ -329,10 +329,16 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		sl.seq4 = c->d_seq4.as<uint64_t>();
 		if (attempt == 0 && (rc = launch_pack4(sl, c->stream))) return rc;
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
+		const int heavy_mult = getenv("BWAHIP_HEAVY_MULT") ? atoi(getenv("BWAHIP_HEAVY_MULT")) : 10;   // x read length; 0 = never hand off
+		if ((rc = c->d_smem_heavy.ensure((size_t)n * 4))) return rc;
+		sl.heavy_list = c->d_smem_heavy.as<int>(); sl.heavy_n = queue + 1; sl.heavy_mult = heavy_mult;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
 		if ((rc = launch_smem(sl, G, c->stream))) return rc;
 		STAGE_LOG("k_smem");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+		if (heavy_mult > 0 && (rc = launch_smem_heavy(sl, c->stream))) return rc;
+		STAGE_LOG("k_smem_heavy");
+		if (timed) HIP_TRY(hipEventRecord(c->ev[10], c->stream));
 		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n);
 		if (timed) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
 		// the number of seeds sizes the next buffers: one 8-byte read-back per batch
@@ -341,6 +347,11 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		HIP_TRY(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (h_err) { fprintf(stderr, "[bwahip] k_smem reported an internal inconsistency\n"); return BWAHIP_EINTERNAL; }
+		if (const char *dump_ext = getenv("BWAHIP_DUMP_EXT")) {   // diagnostic: per-read bwt_extend counts as int32
+			std::vector<int> h_e(n);
+			HIP_TRY(hipMemcpy(h_e.data(), c->d_lrep.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+			if (FILE *fp = fopen(dump_ext, "wb")) { fwrite(h_e.data(), 4, n, fp); fclose(fp); }
+		}
 		// interval-list overflow: the kernel stores the true count; re-run the batch with more room (GPU only, no CPU path)
 		std::vector<int> h_n(n);
 		HIP_TRY(hipMemcpy(h_n.data(), c->d_intv_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -419,7 +430,8 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if (h_err) { fprintf(stderr, "[bwahip] extension kernel reported code %d (reference window or read beyond compiled limits)\n", h_err); return h_err >= 3 ? BWAHIP_ECAPACITY : BWAHIP_EINTERNAL; }
 		if (timed) {
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));
-			HIP_TRY(hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[1], c->ev[10], c->ev[2]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[6], c->ev[1], c->ev[10]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[6]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[4], c->ev[6], c->ev[7]));

@@ -37,6 +37,21 @@ def test_intervals_match_oracle(ctx, small_index, tmp_path, name, n, length, sub
     common.assert_stage_equal(got, want, bw.STAGE_INTV, f"intervals[{name}]")
 
 
+@pytest.mark.parametrize("lanes,heavy_mult", [(1, 10), (2, 10), (4, 10), (8, 10), (2, 0), (2, 1), (1, 2), (4, 3)])
+def test_intervals_every_smem_variant(ctx, small_index, tmp_path, monkeypatch, lanes, heavy_mult):
+    """Every lanes-per-read variant of k_smem, and k_smem_heavy forced onto most reads (heavy_mult 1..3: a read is
+    handed over after heavy_mult x len bwt_extend calls; 0 = never), must give the oracle's interval lists."""
+    monkeypatch.setenv("BWAHIP_SMEM_LANES", str(lanes))
+    monkeypatch.setenv("BWAHIP_HEAVY_MULT", str(heavy_mult))
+    fq, seqs = _reads(small_index, tmp_path, "variants", 2500, 150, 10000, 2000, 2000, 111, 20000)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_INTV]))
+    common.assert_stage_equal(got, want, bw.STAGE_INTV, f"intervals[lanes={lanes},heavy_mult={heavy_mult}]")
+    if heavy_mult in (1, 2, 3):
+        assert ctx.counters()["heavy_intv"] > 0, "k_smem_heavy did not run"
+
+
 MASK_CHAIN_PRE = True
 
 
