@@ -136,8 +136,12 @@ struct ExtLaunch {
 	const int *kept_seeds; int *perm, *perm_counts;   // launch order: reads with many seeds first (nullptr = identity)
 	int *srt;                                    // per-seed-slot scratch (sorted seed order), 2 ints per slot
 	unsigned long long *counters; int *err;
+	// k_extend_spec: best seed of chain ci of read r extended ahead of time into spec_regs[seed_base[r] + ci], for reads with
+	// >= spec_min_chains chains (spec_regs == nullptr: off)
+	DevReg *spec_regs; int2 *spec_items; int *spec_n; int spec_min_chains;
 };
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
+int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st);
 
 int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff,
                    int *out6, hipStream_t st);

@@ -367,6 +367,149 @@ __device__ __forceinline__ void rs_introsort(const RegSort c, int n, int *a, int
 	}
 }
 
+
+// Window of the reference any seed of the chain could reach (bwamem.c:649-664), clamped to the contig of the first
+// seed as bns_fetch_seq does (bntseq.c:426), loaded into LDS as one base per byte.  false: window larger than MAXT.
+__device__ __forceinline__ bool chain_window(const DevIndex &ix, const DevOpt &opt, const DevSeed *seeds, int n, int l_query,
+                                             uint8_t *s_t, int l, int64_t &rmax0_out, int &tl_all_out)
+{
+	const int64_t l_pac = ix.l_pac;
+	int64_t rmax0 = l_pac << 1, rmax1 = 0;
+	for (int i = l; i < n; i += 64) {
+		const DevSeed t = seeds[i];
+		int64_t b = t.rbeg - (t.qbeg + cal_max_gap(opt, t.qbeg));
+		int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(opt, l_query - t.qbeg - t.len));
+		rmax0 = rmax0 < b ? rmax0 : b;
+		rmax1 = rmax1 > e ? rmax1 : e;
+	}
+	rmax0 = wmin64(rmax0); rmax1 = wmax64(rmax1);
+	rmax0 = rmax0 > 0 ? rmax0 : 0;
+	rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+	const int64_t seed0_rbeg = seeds[0].rbeg;
+	if (rmax0 < l_pac && l_pac < rmax1) {
+		if (seed0_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+	}
+	{
+		const bool is_rev = seed0_rbeg >= l_pac;
+		const int rid = dev_pos2rid(ix, is_rev ? (l_pac << 1) - 1 - seed0_rbeg : seed0_rbeg);
+		int64_t far_beg = ix.anns[rid].offset, far_end = far_beg + ix.anns[rid].len;
+		if (is_rev) { int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+		rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+		rmax1 = rmax1 < far_end ? rmax1 : far_end;
+	}
+	const int tl_all = (int)(rmax1 - rmax0);
+	rmax0_out = rmax0; tl_all_out = tl_all;
+	if (tl_all > MAXT) return false;
+	__syncthreads();
+	for (int i = l; i < tl_all; i += 64) s_t[i] = (uint8_t)ref_base(ix, rmax0 + i);
+	return true;
+}
+
+// Extension of one seed into an alignment region (bwamem.c:716-793): left and right ksw_extend2 with band doubling
+// (MAX_BAND_TRY = 2), clip-vs-to-end choice, seed coverage.  Needs s_q / s_t of the chain loaded.
+template <int CPL>
+__device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, const uint8_t *s_q, const uint8_t *s_t, int l_query,
+                                              int64_t rmax0, int tl_all, const DevSeed s, const DevChain &ch, const DevSeed *seeds, int n,
+                                              int l, unsigned long long &cells)
+{
+	DevReg reg;
+	reg.rb = reg.re = 0; reg.frac_rep = 0; reg.qb = reg.qe = 0; reg.sub = reg.csub = reg.sub_n = 0; reg.seedcov = 0;
+	reg.n_comp = 0; reg.is_alt = 0; reg.pad = 0;
+	reg.rid = ch.rid; reg.score = reg.truesc = -1;
+	int aw0 = opt.w, aw1 = opt.w;
+	if (s.qbeg) {                                       // left extension on the reversed prefixes
+		int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
+		const int tlen = (int)(s.rbeg - rmax0);
+		for (int i = 0; i < 2; ++i) {                   // MAX_BAND_TRY
+			const int prev = reg.score;
+			aw0 = opt.w << i;
+			reg.score = wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
+			                       s.len * opt.a, qle, tle, gtle, gscore, max_off, cells);
+			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+		}
+		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
+		else { reg.qb = 0; reg.rb = s.rbeg - gtle; reg.truesc = gscore; }
+	} else { reg.score = reg.truesc = s.len * opt.a; reg.qb = 0; reg.rb = s.rbeg; }
+	if (s.qbeg + s.len != l_query) {                    // right extension
+		int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
+		const int sc0 = reg.score, qe = s.qbeg + s.len, re = (int)(s.rbeg + s.len - rmax0);
+		for (int i = 0; i < 2; ++i) {
+			const int prev = reg.score;
+			aw1 = opt.w << i;
+			reg.score = wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
+			                       qle, tle, gtle, gscore, max_off, cells);
+			if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+		}
+		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
+		else { reg.qe = l_query; reg.re = rmax0 + re + gtle; reg.truesc += gscore - sc0; }
+	} else { reg.qe = l_query; reg.re = s.rbeg + s.len; }
+	int cov = 0;                                        // seedcov (bwamem.c:782-786)
+	for (int i = l; i < n; i += 64) {
+		const DevSeed t = seeds[i];
+		if (t.qbeg >= reg.qb && t.qbeg + t.len <= reg.qe && t.rbeg >= reg.rb && t.rbeg + t.len <= reg.re) cov += t.len;
+	}
+	reg.seedcov = wsum(cov);
+	reg.w = aw0 > aw1 ? aw0 : aw1;
+	reg.seedlen0 = s.len;
+	reg.frac_rep = ch.frac_rep;
+	return reg;
+}
+
+// K4a -- reads with many chains (hundreds, inside large repeat families) would keep one wavefront busy for tens of
+// milliseconds while the rest of the GPU idles.  What k_extend must do in order is only the *decision* whether a seed
+// is extended (it looks at the regions found so far); the extension itself depends on nothing but the seed and its
+// chain.  So the best seed of every chain of such a read is extended here, one wavefront per chain, and k_extend
+// picks the result up.  (A best seed that k_extend then skips was extended in vain; its result is never looked at.)
+template <int CPL>
+__global__ __launch_bounds__(64) void k_extend_spec(ExtLaunch a)
+{
+	__shared__ uint8_t s_q[MAXQ + 8];
+	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ int8_t s_mat[32];
+	const int l = lane();
+	const DevOpt &opt = a.opt;
+	const DevIndex &ix = a.ix;
+	Sw sw; sw.mat = s_mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins;
+	if (l < 25) s_mat[l] = opt.mat[l];
+	unsigned long long cells = 0;
+	const int n_items = *a.spec_n;
+	for (int it = (int)blockIdx.x; it < n_items; it += (int)gridDim.x) {
+		const int2 item = a.spec_items[it];
+		const int r = item.x, ci = item.y;
+		const int l_query = (int)(a.off[r + 1] - a.off[r]);
+		const uint8_t *query = a.seq + a.off[r];
+		const int64_t sb = a.seed_base[r];
+		__syncthreads();
+		for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
+		const DevChain ch = a.chains[sb + ci];
+		const DevSeed *seeds = a.chain_seeds + sb + ch.seed_off;
+		const int n = ch.n;
+		if (n == 0) continue;
+		int64_t rmax0; int tl_all;
+		if (!chain_window(ix, opt, seeds, n, l_query, s_t, l, rmax0, tl_all)) continue;   // k_extend reports the error
+		// the seed k_extend takes first: largest (score, index) (bwamem.c:669-674)
+		long long best = -1;
+		for (int i = l; i < n; i += 64) { const long long key = (long long)seeds[i].score << 32 | i; best = key > best ? key : best; }
+		best = wmax64(best);
+		const DevSeed s = seeds[(int)(best & 0xffffffff)];
+		__syncthreads();
+		const DevReg reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, cells);
+		if (l == 0) a.spec_regs[sb + ci] = reg;
+	}
+	if (l == 0 && cells) atomicAdd(&a.counters[CNT_CELLS], cells);
+}
+
+// work list of k_extend_spec: (read, chain) for every chain of a read with at least min_chains chains
+__global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *items, int *n_items)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const int nc = chain_n[r];
+	if (nc < min_chains) return;
+	const int base = atomicAdd(n_items, nc);
+	for (int ci = 0; ci < nc; ++ci) items[base + ci] = make_int2(r, ci);
+}
+
 template <int CPL>
 __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 {
@@ -382,6 +525,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	const int64_t sb = a.seed_base[r], rb0 = a.reg_base[r];
 	const int n_chains = a.chain_n[r];
 	const int64_t l_pac = ix.l_pac;
+	const bool use_spec = a.spec_regs && n_chains >= a.spec_min_chains;
 	DevReg *av = a.regs + rb0;                                  // the read's region list (av of bwamem.c:639)
 	int *srt = a.srt + 2 * sb;                                  // [0..n): seed index in ascending (score,idx) order; [n..2n): skipped flag
 	int n_av = 0;
@@ -397,35 +541,8 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 		const DevSeed *seeds = a.chain_seeds + sb + ch.seed_off;
 		const int n = ch.n;
 		if (n == 0) continue;
-		// ---- widest window any seed could reach (bwamem.c:649-664)
-		int64_t rmax0 = l_pac << 1, rmax1 = 0;
-		for (int i = l; i < n; i += 64) {
-			const DevSeed t = seeds[i];
-			int64_t b = t.rbeg - (t.qbeg + cal_max_gap(opt, t.qbeg));
-			int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(opt, l_query - t.qbeg - t.len));
-			rmax0 = rmax0 < b ? rmax0 : b;
-			rmax1 = rmax1 > e ? rmax1 : e;
-		}
-		rmax0 = wmin64(rmax0); rmax1 = wmax64(rmax1);
-		rmax0 = rmax0 > 0 ? rmax0 : 0;
-		rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-		const int64_t seed0_rbeg = seeds[0].rbeg;
-		if (rmax0 < l_pac && l_pac < rmax1) {
-			if (seed0_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
-		}
-		// ---- bns_fetch_seq (bntseq.c:426): clamp to the contig of the first seed, load the window into LDS
-		{
-			const bool is_rev = seed0_rbeg >= l_pac;
-			const int rid = dev_pos2rid(ix, is_rev ? (l_pac << 1) - 1 - seed0_rbeg : seed0_rbeg);
-			int64_t far_beg = ix.anns[rid].offset, far_end = far_beg + ix.anns[rid].len;
-			if (is_rev) { int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
-			rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
-			rmax1 = rmax1 < far_end ? rmax1 : far_end;
-		}
-		const int tl_all = (int)(rmax1 - rmax0);
-		if (tl_all > MAXT) { if (l == 0) atomicExch(a.err, 3); break; }
-		__syncthreads();
-		for (int i = l; i < tl_all; i += 64) s_t[i] = (uint8_t)ref_base(ix, rmax0 + i);
+		int64_t rmax0; int tl_all;
+		if (!chain_window(ix, opt, seeds, n, l_query, s_t, l, rmax0, tl_all)) { if (l == 0) atomicExch(a.err, 3); break; }
 		// ---- seeds in ascending (score<<32|index) order (bwamem.c:669-672; keys are unique, any sort does)
 		for (int i = l; i < n; i += 64) {
 			const int sc = seeds[i].score;
@@ -482,47 +599,11 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 				}
 				if (!any) { if (l == 0) srt[n + sidx] = 1; __threadfence_block(); __syncthreads(); continue; }
 			}
-			// ---- extend (bwamem.c:716-793)
+			// ---- extend (bwamem.c:716-793); the best seed of every chain of a many-chain read was extended ahead of
+			// time by k_extend_spec (its result does not depend on the regions found so far, only the decision above does)
 			DevReg reg;
-			reg.rb = reg.re = 0; reg.frac_rep = 0; reg.qb = reg.qe = 0; reg.sub = reg.csub = reg.sub_n = 0; reg.seedcov = 0;
-			reg.n_comp = 0; reg.is_alt = 0; reg.pad = 0;
-			reg.rid = ch.rid; reg.score = reg.truesc = -1;
-			int aw0 = opt.w, aw1 = opt.w;
-			if (s.qbeg) {                                       // left extension on the reversed prefixes
-				int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
-				const int tlen = (int)(s.rbeg - rmax0);
-				for (int i = 0; i < 2; ++i) {                   // MAX_BAND_TRY
-					const int prev = reg.score;
-					aw0 = opt.w << i;
-					reg.score = wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-					                       s.len * opt.a, qle, tle, gtle, gscore, max_off, cells);
-					if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
-				}
-				if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
-				else { reg.qb = 0; reg.rb = s.rbeg - gtle; reg.truesc = gscore; }
-			} else { reg.score = reg.truesc = s.len * opt.a; reg.qb = 0; reg.rb = s.rbeg; }
-			if (s.qbeg + s.len != l_query) {                    // right extension
-				int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
-				const int sc0 = reg.score, qe = s.qbeg + s.len, re = (int)(s.rbeg + s.len - rmax0);
-				for (int i = 0; i < 2; ++i) {
-					const int prev = reg.score;
-					aw1 = opt.w << i;
-					reg.score = wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-					                       qle, tle, gtle, gscore, max_off, cells);
-					if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-				}
-				if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
-				else { reg.qe = l_query; reg.re = rmax0 + re + gtle; reg.truesc += gscore - sc0; }
-			} else { reg.qe = l_query; reg.re = s.rbeg + s.len; }
-			int cov = 0;                                        // seedcov (bwamem.c:782-786)
-			for (int i = l; i < n; i += 64) {
-				const DevSeed t = seeds[i];
-				if (t.qbeg >= reg.qb && t.qbeg + t.len <= reg.qe && t.rbeg >= reg.rb && t.rbeg + t.len <= reg.re) cov += t.len;
-			}
-			reg.seedcov = wsum(cov);
-			reg.w = aw0 > aw1 ? aw0 : aw1;
-			reg.seedlen0 = s.len;
-			reg.frac_rep = ch.frac_rep;
+			if (use_spec && k == n - 1) reg = a.spec_regs[sb + ci];
+			else reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, cells);
 			if (l == 0) av[n_av] = reg;
 			++n_av;
 			__threadfence_block();
@@ -720,6 +801,18 @@ int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q
 {
 	if (n <= 0) return 0;
 	hipLaunchKernelGGL(k_kat_ksw, dim3(n), dim3(64), 0, st, opt, n, params, q, qoff, t, toff, out6);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st)
+{
+	if (a.n_reads <= 0 || !a.spec_regs) return 0;
+	(void)hipMemsetAsync(a.spec_n, 0, 4, st);
+	hipLaunchKernelGGL(k_spec_items, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.chain_n, a.spec_min_chains, a.spec_items, a.spec_n);
+	const int grid = 16384;
+	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend_spec<3>, dim3(grid), dim3(64), 0, st, a);
+	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend_spec<5>, dim3(grid), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_extend_spec<11>, dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 

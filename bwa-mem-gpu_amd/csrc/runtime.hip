@@ -45,7 +45,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, int64_t *out, int 
 }
 } // namespace
 
-static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy" };
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec" };
 
 struct bwahip_ctx {
 	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
@@ -63,7 +63,7 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items;
 	int intv_cap = 96;
 	int64_t total_seeds = 0, total_regs = 0;
 	hipEvent_t ev[16];
@@ -216,7 +216,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm };
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -420,6 +420,15 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = c->d_perm.ensure((size_t)(n + 4) * 4))) return rc;
 		el.kept_seeds = c->d_kept_seeds.as<int>(); el.perm = c->d_perm.as<int>() + 4; el.perm_counts = c->d_perm.as<int>();
 		el.counters = counters; el.err = err;
+		const int spec_min = getenv("BWAHIP_SPEC_MIN_CHAINS") ? atoi(getenv("BWAHIP_SPEC_MIN_CHAINS")) : 16;   // 0 = no ahead-of-time extension
+		if (spec_min > 0) {
+			if ((rc = c->d_spec_regs.ensure(T * sizeof(DevReg))) || (rc = c->d_spec_items.ensure(T * 8 + 16))) return rc;
+			el.spec_regs = c->d_spec_regs.as<DevReg>(); el.spec_n = c->d_spec_items.as<int>(); el.spec_items = (int2*)(c->d_spec_items.as<int>() + 4);
+			el.spec_min_chains = spec_min;
+		}
+		if (timed) HIP_TRY(hipEventRecord(c->ev[11], c->stream));
+		if ((rc = launch_extend_spec(el, c->max_len, c->stream))) return rc;
+		STAGE_LOG("k_extend_spec");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[8], c->stream));
 		if (verbose) fprintf(stderr, "[bwahip] seeds=%lld regs_cap=%lld\n", (long long)total, (long long)total_regs);
 		if ((rc = launch_extend(el, c->max_len, c->stream))) return rc;
@@ -436,6 +445,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[6]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[4], c->ev[6], c->ev[7]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[5], c->ev[8], c->ev[9]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[7], c->ev[11], c->ev[8]));
 		}
 		return 0;
 	}

@@ -86,6 +86,19 @@ def test_all_stages_match_oracle(ctx, small_index, tmp_path, name, n, length, su
         common.assert_stage_equal(got, want, st, f"{what}[{name}]")
 
 
+@pytest.mark.parametrize("spec_min", [0, 1, 2])
+def test_regions_with_forced_ahead_of_time_extension(ctx, small_index, tmp_path, monkeypatch, spec_min):
+    """k_extend_spec (best seed of each chain extended by its own wavefront before k_extend decides) forced onto every
+    read with >= spec_min chains (1: all reads; 0: switched off): regions before and after dedup must not change."""
+    monkeypatch.setenv("BWAHIP_SPEC_MIN_CHAINS", str(spec_min))
+    fq, seqs = _reads(small_index, tmp_path, "spec", 3000, 150, 20000, 3000, 500, 113, 30000)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_REGS_PRE, bw.STAGE_REGS]))
+    common.assert_stage_equal(got, want, bw.STAGE_REGS_PRE, f"regions before dedup[spec_min={spec_min}]")
+    common.assert_stage_equal(got, want, bw.STAGE_REGS, f"regions[spec_min={spec_min}]")
+
+
 def test_fm_known_answers_vs_oracle_lib(ctx, small_index):
     """Device Occ / SA / extend against the oracle's C functions on random rows."""
     import ctypes as C
