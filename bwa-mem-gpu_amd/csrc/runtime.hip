@@ -23,25 +23,75 @@ struct DevBuf {
 };
 
 namespace {
-// exclusive scan int32 -> int64 (n+1 outputs), one workgroup; n is at most a few million per batch
-__global__ __launch_bounds__(1024) void k_scan(const int *in, int64_t *out, int n)
+// exclusive scan int32 -> int64 (n+1 outputs) in three small launches: tile sums, scan of the tile sums, tile scans
+constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_TILE = SCAN_T * SCAN_PER;
+
+__device__ __forceinline__ long long block_excl_scan(long long v, long long *sh, long long *total)
 {
-	__shared__ long long part[1024];
-	const int t = threadIdx.x, per = (n + 1023) / 1024;
-	const int b = t * per, e = b + per < n ? b + per : n;
-	long long s = 0;
-	for (int i = b; i < e; ++i) s += in[i];
-	part[t] = s;
+	const int t = threadIdx.x;
+	sh[t] = v;
 	__syncthreads();
-	for (int d = 1; d < 1024; d <<= 1) {
-		long long v = t >= d ? part[t - d] : 0;
+	for (int d = 1; d < SCAN_T; d <<= 1) {
+		long long o = t >= d ? sh[t - d] : 0;
 		__syncthreads();
-		part[t] += v;
+		sh[t] += o;
 		__syncthreads();
 	}
-	long long run = part[t] - s;
-	for (int i = b; i < e; ++i) { out[i] = run; run += in[i]; }
-	if (t == 1023) out[n] = part[1023];
+	const long long incl = sh[t];
+	*total = sh[SCAN_T - 1];
+	__syncthreads();
+	return incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(const int *in, long long *sums, int n)
+{
+	__shared__ long long sh[SCAN_T];
+	const int b = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER;
+	long long s = 0;
+	for (int i = 0; i < SCAN_PER; ++i) if (b + i < n) s += in[b + i];
+	long long total;
+	block_excl_scan(s, sh, &total);
+	if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_top(long long *sums, int n_tiles, int64_t *out_total)
+{
+	__shared__ long long sh[SCAN_T];
+	long long run = 0;
+	for (int base = 0; base < n_tiles; base += SCAN_T) {
+		const int i = base + threadIdx.x;
+		const long long v = i < n_tiles ? sums[i] : 0;
+		long long total;
+		const long long ex = block_excl_scan(v, sh, &total);
+		if (i < n_tiles) sums[i] = run + ex;
+		run += total;
+	}
+	if (threadIdx.x == 0) *out_total = run;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_tiles(const int *in, const long long *sums, int64_t *out, int n)
+{
+	__shared__ long long sh[SCAN_T];
+	const int b = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER;
+	int v[SCAN_PER];
+	long long s = 0;
+#pragma unroll
+	for (int i = 0; i < SCAN_PER; ++i) { v[i] = b + i < n ? in[b + i] : 0; s += v[i]; }
+	long long total;
+	long long run = sums[blockIdx.x] + block_excl_scan(s, sh, &total);
+#pragma unroll
+	for (int i = 0; i < SCAN_PER; ++i) { if (b + i < n) out[b + i] = run; run += v[i]; }
+}
+
+int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st)
+{
+	const int tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+	int rc = tmp.ensure((size_t)(tiles + 1) * 8);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_scan_sums, dim3(tiles), dim3(SCAN_T), 0, st, in, tmp.as<long long>(), n);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, st, tmp.as<long long>(), tiles, out + n);
+	hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_T), 0, st, in, tmp.as<long long>(), out, n);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 } // namespace
 
@@ -63,7 +113,7 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan;
 	int intv_cap = 96;
 	int64_t total_seeds = 0, total_regs = 0;
 	hipEvent_t ev[16];
@@ -216,7 +266,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items };
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -339,7 +389,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if (heavy_mult > 0 && (rc = launch_smem_heavy(sl, c->stream))) return rc;
 		STAGE_LOG("k_smem_heavy");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[10], c->stream));
-		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n);
+		if ((rc = launch_scan(c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
 		// the number of seeds sizes the next buffers: one 8-byte read-back per batch
 		int64_t total = 0; int h_err = 0;
@@ -399,7 +449,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = launch_chain_flt(cl, c->stream))) return rc;
 		STAGE_LOG("k_chain");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
-		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_kept_seeds.as<int>(), c->d_reg_base.as<int64_t>(), n);
+		if ((rc = launch_scan(c->d_kept_seeds.as<int>(), c->d_reg_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[7], c->stream));
 		int64_t total_regs = 0;
 		HIP_TRY(hipMemcpyAsync(&total_regs, c->d_reg_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
