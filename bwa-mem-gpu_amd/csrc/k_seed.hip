@@ -4,8 +4,8 @@
 //
 // All look-ups of a batch are independent, so they are flattened: an exclusive scan of the per-read
 // look-up counts (written by K1) gives every seed a fixed slot, in exactly the order the reference
-// visits them (interval order, then k), and one quad of lanes resolves one seed: up to sa_intv-1
-// dependent LF steps (bwt.c:53), each one fully used 64-byte gather, then one 8-byte SA read.
+// visits them (interval order, then k).  Three small kernels: k_seed_rows lays the BWT rows out in the slots,
+// k_seed_walk resolves them (one lane per look-up), k_seed_rid adds the contig id.
 // Also holds the known-answer kernels the parity tests drive (bwahip_kat_*).
 #include "fmi_dev.h"
 
@@ -49,46 +49,69 @@ __device__ __forceinline__ uint64_t quad_sa(const DevIndex &ix, uint64_t k, bool
 	return live ? steps + ix.sa[k >> ix.sa_shift] : 0;
 }
 
-__global__ __launch_bounds__(256) void k_seeds(SeedLaunch a, long long total)
+// K2a -- one thread per read lays out its look-ups: slot seed_base[r] + running index holds the BWT row to resolve
+// (kept in the rbeg field until K2b overwrites it) and the seed's query interval, in the order the reference visits
+// them (interval order, then k; bwamem.c:283-290).
+__global__ __launch_bounds__(256) void k_seed_rows(SeedLaunch a)
 {
-	const long long quad0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-	const long long n_quads = ((long long)gridDim.x * blockDim.x) >> 2;
-	const int r4 = lane_id() & 3;
-	unsigned long long n_lf = 0, n_sa = 0;
-	const long long rounds = (total + n_quads - 1) / n_quads;
-	for (long long it = 0; it < rounds; ++it) {              // same trip count for every lane: the DPP steps stay convergent
-		long long sid = quad0 + it * n_quads;
-		bool live = sid < total;
-		uint64_t row = 0; int qbeg = 0, slen = 0;
-		if (live) {
-			int lo = 0, hi = a.n_reads;                      // largest r with seed_base[r] <= sid
-			while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.seed_base[mid] <= sid) lo = mid; else hi = mid; }
-			int r = lo, o = (int)(sid - a.seed_base[r]), n = a.intv_n[r];
-			const DevIntv *iv = a.intv + (size_t)r * a.cap;
-			for (int t = 0; t < n; ++t) {
-				uint64_t x2 = iv[t].x2;
-				uint64_t step = x2 > (uint64_t)a.opt.max_occ ? x2 / a.opt.max_occ : 1;
-				uint64_t cnt = (x2 + step - 1) / step;
-				if (cnt > (uint64_t)a.opt.max_occ) cnt = a.opt.max_occ;
-				if ((uint64_t)o < cnt) {
-					uint64_t info = iv[t].info;
-					row = iv[t].x0 + (uint64_t)o * step;
-					qbeg = (int)(info >> 32); slen = (int)(uint32_t)info - qbeg;
-					break;
-				}
-				o -= (int)cnt;
-			}
-		}
-		uint64_t rbeg = quad_sa(a.ix, row, live, n_lf);
-		if (live && r4 == 0) {
-			DevSeed sd;
-			sd.rbeg = (int64_t)rbeg; sd.qbeg = qbeg; sd.len = slen; sd.score = slen;
-			sd.rid = dev_intv2rid(a.ix, sd.rbeg, sd.rbeg + slen);
-			a.seeds[sid] = sd;
-			++n_sa;
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.n_reads) return;
+	const long long base = a.seed_base[r], end = a.seed_base[r + 1];
+	if (end == base) return;                                 // also covers reads whose interval list overflowed
+	const int n = a.intv_n[r];
+	const DevIntv *iv = a.intv + (size_t)r * a.cap;
+	long long sid = base;
+	for (int t = 0; t < n; ++t) {
+		const uint64_t x0 = iv[t].x0, x2 = iv[t].x2, info = iv[t].info;
+		const uint64_t step = x2 > (uint64_t)a.opt.max_occ ? x2 / a.opt.max_occ : 1;   // bwamem.c:285
+		DevSeed sd;
+		sd.qbeg = (int)(info >> 32); sd.len = (int)(uint32_t)info - sd.qbeg; sd.score = sd.len; sd.rid = 0;
+		int count = 0;
+		for (uint64_t kk = 0; kk < x2 && count < a.opt.max_occ; kk += step, ++count) {   // bwamem.c:286
+			sd.rbeg = (int64_t)(x0 + kk);
+			a.seeds[sid++] = sd;
 		}
 	}
-	if (r4 == 0 && n_sa) { atomicAdd(&a.counters[CNT_SA], n_sa); atomicAdd(&a.counters[CNT_LF], n_lf); atomicAdd(&a.counters[CNT_SEEDS], n_sa); }
+}
+
+// K2b -- bwt_sa (bwt.c:86): one lane per look-up, every lane walking on its own: up to sa_intv-1 dependent LF steps
+// (bwt.c:53), each one whole 64-byte Occ block read by the lane itself, then one 8-byte SA read.  A lane that
+// finishes takes its next slot at once (the row was prefetched), so the wavefront never waits for its slowest walk.
+__global__ __launch_bounds__(256) void k_seed_walk(SeedLaunch a, long long total)
+{
+	const DevIndex &ix = a.ix;
+	const long long n_lanes = (long long)gridDim.x * blockDim.x;
+	long long next = (long long)blockIdx.x * blockDim.x + threadIdx.x, sid = 0;
+	const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+	uint64_t k = 0, k_pref = next < total ? (uint64_t)a.seeds[next].rbeg : 0;
+	unsigned steps = 0, n_lf = 0, n_sa = 0;
+	bool have = false;
+	for (;;) {
+		if (!have && next < total) {
+			sid = next; k = k_pref; steps = 0; have = true;
+			next += n_lanes;
+			if (next < total) k_pref = (uint64_t)a.seeds[next].rbeg;
+		}
+		if (__ballot(have) == 0) break;
+		const bool fin = have && (k & mask) == 0;
+		const bool walk = have && !fin;
+		const uint64_t sa_v = ix.sa[fin ? k >> ix.sa_shift : 0];   // both gathers are issued before either is waited for
+		const uint64_t nk = lane_lf(ix, walk ? k : 0);
+		if (fin) { a.seeds[sid].rbeg = (int64_t)(steps + sa_v); have = false; ++n_sa; }
+		if (walk) { n_lf += k != ix.primary; k = nk; ++steps; }
+	}
+	unsigned long long lf = n_lf, sa = n_sa;
+	for (int m = 32; m; m >>= 1) { lf += __shfl_xor(lf, m); sa += __shfl_xor(sa, m); }
+	if (lane_id() == 0 && sa) { atomicAdd(&a.counters[CNT_SA], sa); atomicAdd(&a.counters[CNT_LF], lf); atomicAdd(&a.counters[CNT_SEEDS], sa); }
+}
+
+// K2c -- contig id of every seed (bns_intv2rid, bntseq.c:370, as called at bwamem.c:293)
+__global__ __launch_bounds__(256) void k_seed_rid(SeedLaunch a, long long total)
+{
+	const long long sid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (sid >= total) return;
+	const int64_t rbeg = a.seeds[sid].rbeg;
+	a.seeds[sid].rid = dev_intv2rid(a.ix, rbeg, rbeg + a.seeds[sid].len);
 }
 
 // ------------------------------------------------------------- known-answer kernels
@@ -125,10 +148,11 @@ __global__ void k_kat_extend(DevIndex ix, int n, const uint64_t *ik3, const int 
 int launch_seeds(const SeedLaunch &a, int64_t total, hipStream_t st)
 {
 	if (total <= 0) return 0;
-	long long quads = total;
-	long long blocks = (quads * 4 + 255) / 256;
-	if (blocks > 256 * 32) blocks = 256 * 32;                 // grid-stride the rest
-	hipLaunchKernelGGL(k_seeds, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
+	hipLaunchKernelGGL(k_seed_rows, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
+	long long blocks = (total + 255) / 256;
+	if (blocks > 256 * 8) blocks = 256 * 8;                   // 8 waves per SIMD resident; lanes stride over the rest
+	hipLaunchKernelGGL(k_seed_walk, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
+	hipLaunchKernelGGL(k_seed_rid, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, (long long)total);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 int launch_kat_occ4(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st)

@@ -52,7 +52,7 @@ static void run(const uint4 *tab, uint64_t nblk, int waves_per_cu, int steps, ui
 	fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
 	const uint64_t max_bytes = 8ull << 30;
 	uint4 *tab; unsigned long long *sink; uint4 *scratch;
@@ -61,6 +61,11 @@ int main()
 	const uint64_t per_lane = 256;                         // 4 KB of scratch per lane
 	hipMalloc(&scratch, (size_t)256 * 32 * 64 * per_lane * 16);
 	hipMemset(tab, 0x5a, max_bytes);
+	if (argc > 1) {                                          // calibration run for the FETCH_SIZE counter: known bytes = gathers x 64
+		run<1, 0>(tab, 3072ull * (1ull << 20) / 64, 16, 400, scratch, per_lane, sink, "calibration: dependent gather");
+		printf("known bytes of the timed dispatch: %.0f (and a quarter of that for the warm-up dispatch)\n", 256.0 * 16 * 64 * 400 * 64);
+		return 0;
+	}
 	for (uint64_t mb : { 64ull, 512ull, 3072ull, 8192ull }) {
 		uint64_t nblk = mb * (1ull << 20) / 64;
 		run<1, 0>(tab, nblk, 16, 400, scratch, per_lane, sink, "dependent gather");
