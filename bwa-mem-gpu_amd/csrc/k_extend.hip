@@ -423,8 +423,11 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 		for (int i = 0; i < 2; ++i) {                   // MAX_BAND_TRY
 			const int prev = reg.score;
 			aw0 = opt.w << i;
-			reg.score = wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                       s.len * opt.a, qle, tle, gtle, gscore, max_off, cells);
+			// a flank of at most 63 bases fits one column per lane: less than half the instructions per row
+			reg.score = s.qbeg < 64 ? wave_extend<1>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
+			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, cells)
+			                        : wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
+			                                           s.len * opt.a, qle, tle, gtle, gscore, max_off, cells);
 			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
@@ -436,8 +439,10 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 		for (int i = 0; i < 2; ++i) {
 			const int prev = reg.score;
 			aw1 = opt.w << i;
-			reg.score = wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                       qle, tle, gtle, gscore, max_off, cells);
+			reg.score = l_query - qe < 64 ? wave_extend<1>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
+			                                               qle, tle, gtle, gscore, max_off, cells)
+			                              : wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
+			                                                 qle, tle, gtle, gscore, max_off, cells);
 			if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
