@@ -104,8 +104,8 @@ struct SeedLaunch {
 };
 int launch_seeds(const SeedLaunch &a, int64_t total_seeds, hipStream_t st);
 
-struct BtNodeOpaque { int w[26]; };              // sizeof(BtNode) in k_chain.hip (2 + 11 + 12 ints, padded)
-struct ChainWOpaque { int64_t pos; int a, b, c, d; };
+struct BtNodeOpaque { int w[48]; };              // sizeof(BtNode) in k_chain.hip (2 + 11 + 12 ints, pad, 11 x int64)
+struct ChainWOpaque { int64_t pos; int a, b, c, d; int64_t e; int f, g, h, i; };
 struct ChainLaunch {
 	DevIndex ix; DevOpt opt;
 	int n_reads; const int64_t *off;

@@ -15,9 +15,13 @@ namespace {
 constexpr int BT_T = 6, BT_MAXK = 2 * BT_T - 1;              // kbtree.h:59 with sizeof(mem_chain_t) = 32
 constexpr int FLT_SEQ_MAX = 32;                              // more chains than this: filter in k_chain_flt
 
-struct BtNode { int is_internal, n; int key[BT_MAXK]; int ptr[BT_MAXK + 1]; int pad; };
+// every key carries a copy of its chain's pos so that the search inside a node reads the node only: one memory
+// latency per level instead of one per binary-search probe (the probes chased cw[key].pos through HBM/L2)
+struct BtNode { int is_internal, n; int key[BT_MAXK]; int ptr[BT_MAXK + 1]; int pad; int64_t pos[BT_MAXK]; };
 static_assert(sizeof(BtNode) == sizeof(BtNodeOpaque), "BtNode layout");
-struct ChainW { int64_t pos; int head, tail, n, rid; };      // chain under construction: seeds as a linked list
+// chain under construction: seeds as a linked list; the query/reference ends test_and_merge and the filter look at
+// are cached here (first seed: qbeg, rbeg == pos; last seed: qbeg, len, rbeg) to save a dependent seed fetch
+struct ChainW { int64_t pos; int head, tail, n, rid; int64_t last_rbeg; int first_qbeg, last_qbeg, last_len, pad; };
 static_assert(sizeof(ChainW) == sizeof(ChainWOpaque), "ChainW layout");
 
 struct ReadCtx {
@@ -30,17 +34,23 @@ struct ReadCtx {
 
 __device__ __forceinline__ int cmp_pos(int64_t a, int64_t b) { return (b < a) - (a < b); }
 
-// kbtree.h:119 __kb_getp_aux
+// kbtree.h:119 __kb_getp_aux.  The binary search over sorted keys returns the number of keys below `pos`; counting
+// them directly gives the same index without dependent probes or dynamic register indexing.
 __device__ int bt_find(const ReadCtx &c, const BtNode *x, int64_t pos, int *r)
 {
-	int begin = 0, end = x->n;
-	if (x->n == 0) return -1;
-	while (begin < end) {
-		int mid = (begin + end) >> 1;
-		if (c.cw[x->key[mid]].pos < pos) begin = mid + 1; else end = mid;
+	const int n = x->n;
+	if (n == 0) return -1;
+	int begin = 0;
+	int64_t pb = 0;
+#pragma unroll
+	for (int m = 0; m < BT_MAXK; ++m) {
+		const int64_t pm = x->pos[m];
+		begin += (m < n && pm < pos) ? 1 : 0;
 	}
-	if (begin == x->n) { *r = 1; return x->n - 1; }
-	*r = cmp_pos(pos, c.cw[x->key[begin]].pos);
+	if (begin == n) { *r = 1; return n - 1; }
+#pragma unroll
+	for (int m = 0; m < BT_MAXK; ++m) pb = m == begin ? x->pos[m] : pb;
+	*r = cmp_pos(pos, pb);
 	if (*r < 0) --begin;
 	return begin;
 }
@@ -72,13 +82,13 @@ __device__ void bt_split(ReadCtx &c, int xi, int i, int yi)
 	int zi = bt_new(c, c.nodes[yi].is_internal);
 	BtNode *x = &c.nodes[xi], *y = &c.nodes[yi], *z = &c.nodes[zi];
 	z->n = BT_T - 1;
-	for (int k = 0; k < BT_T - 1; ++k) z->key[k] = y->key[k + BT_T];
+	for (int k = 0; k < BT_T - 1; ++k) { z->key[k] = y->key[k + BT_T]; z->pos[k] = y->pos[k + BT_T]; }
 	if (y->is_internal) for (int k = 0; k < BT_T; ++k) z->ptr[k] = y->ptr[k + BT_T];
 	y->n = BT_T - 1;
 	for (int k = x->n; k > i; --k) x->ptr[k + 1] = x->ptr[k];
 	x->ptr[i + 1] = zi;
-	for (int k = x->n - 1; k >= i; --k) x->key[k + 1] = x->key[k];
-	x->key[i] = y->key[BT_T - 1];
+	for (int k = x->n - 1; k >= i; --k) { x->key[k + 1] = x->key[k]; x->pos[k + 1] = x->pos[k]; }
+	x->key[i] = y->key[BT_T - 1]; x->pos[i] = y->pos[BT_T - 1];
 	++x->n;
 }
 
@@ -98,8 +108,8 @@ __device__ void bt_put(ReadCtx &c, int k)
 		int r = 0;
 		if (!x->is_internal) {
 			int i = bt_find(c, x, pos, &r);
-			for (int t = x->n - 1; t > i; --t) x->key[t + 1] = x->key[t];
-			x->key[i + 1] = k;
+			for (int t = x->n - 1; t > i; --t) { x->key[t + 1] = x->key[t]; x->pos[t + 1] = x->pos[t]; }
+			x->key[i + 1] = k; x->pos[i + 1] = pos;
 			++x->n;
 			return;
 		}
@@ -107,7 +117,7 @@ __device__ void bt_put(ReadCtx &c, int k)
 		if (c.nodes[x->ptr[i]].n == BT_MAXK) {
 			bt_split(c, xi, i, x->ptr[i]);
 			x = &c.nodes[xi];
-			if (pos > c.cw[x->key[i]].pos) ++i;
+			if (pos > x->pos[i]) ++i;
 		}
 		xi = x->ptr[i];
 	}
@@ -137,17 +147,19 @@ __device__ int bt_inorder(const ReadCtx &c, int *out)
 }
 
 // bwamem.c:197 test_and_merge
-__device__ bool try_merge(ReadCtx &c, const DevOpt &opt, int64_t l_pac, int ci, int si)
+__device__ bool try_merge(ReadCtx &c, const DevOpt &opt, int64_t l_pac, int ci, int si, const DevSeed p)
 {
 	ChainW *ch = &c.cw[ci];
-	const DevSeed p = c.seeds[si], first = c.seeds[ch->head], last = c.seeds[ch->tail];
-	int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
-	if (p.rid != ch->rid) return false;
-	if (p.qbeg >= first.qbeg && p.qbeg + p.len <= qend && p.rbeg >= first.rbeg && p.rbeg + p.len <= rend) return true;
-	if ((last.rbeg < l_pac || first.rbeg < l_pac) && p.rbeg >= l_pac) return false;
-	int64_t x = p.qbeg - last.qbeg, y = p.rbeg - last.rbeg;
-	if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - last.len < opt.max_chain_gap && y - last.len < opt.max_chain_gap) {
-		c.nxt[ch->tail] = si; c.nxt[si] = -1; ch->tail = si; ++ch->n;
+	const ChainW w = *ch;
+	const int64_t first_rbeg = w.pos;                           // the chain's pos is its first seed's rbeg (bwamem.c:304)
+	int64_t qend = w.last_qbeg + w.last_len, rend = w.last_rbeg + w.last_len;
+	if (p.rid != w.rid) return false;
+	if (p.qbeg >= w.first_qbeg && p.qbeg + p.len <= qend && p.rbeg >= first_rbeg && p.rbeg + p.len <= rend) return true;
+	if ((w.last_rbeg < l_pac || first_rbeg < l_pac) && p.rbeg >= l_pac) return false;
+	int64_t x = p.qbeg - w.last_qbeg, y = p.rbeg - w.last_rbeg;
+	if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - w.last_len < opt.max_chain_gap && y - w.last_len < opt.max_chain_gap) {
+		c.nxt[w.tail] = si; c.nxt[si] = -1;
+		ch->tail = si; ch->n = w.n + 1; ch->last_rbeg = p.rbeg; ch->last_qbeg = p.qbeg; ch->last_len = p.len;
 		return true;
 	}
 	return false;
@@ -234,8 +246,8 @@ __device__ void isort_weight(const ReadCtx &c, int n, int *a)
 }
 #undef W_LT
 
-__device__ __forceinline__ int chn_beg(const ReadCtx &c, int ci) { return c.seeds[c.cw[ci].head].qbeg; }
-__device__ __forceinline__ int chn_end(const ReadCtx &c, int ci) { const DevSeed d = c.seeds[c.cw[ci].tail]; return d.qbeg + d.len; }
+__device__ __forceinline__ int chn_beg(const ReadCtx &c, int ci) { return c.cw[ci].first_qbeg; }
+__device__ __forceinline__ int chn_end(const ReadCtx &c, int ci) { return c.cw[ci].last_qbeg + c.cw[ci].last_len; }
 
 __device__ void write_chains(const ReadCtx &c, const DevIndex &ix, int n, const int *order, float frac_rep, bool with_flt,
                              DevChain *oc, DevSeed *os)
@@ -293,11 +305,12 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 		bool to_add = true;
 		if (c.n_chains) {
 			int lower = bt_lower(c, sd.rbeg);
-			if (lower >= 0 && try_merge(c, a.opt, a.ix.l_pac, lower, si)) to_add = false;
+			if (lower >= 0 && try_merge(c, a.opt, a.ix.l_pac, lower, si, sd)) to_add = false;
 		}
 		if (to_add) {
 			ChainW *ch = &c.cw[c.n_chains];
 			ch->pos = sd.rbeg; ch->head = ch->tail = si; ch->n = 1; ch->rid = sd.rid;
+			ch->last_rbeg = sd.rbeg; ch->first_qbeg = ch->last_qbeg = sd.qbeg; ch->last_len = sd.len; ch->pad = 0;
 			c.nxt[si] = -1;
 			bt_put(c, c.n_chains++);
 		}
