@@ -145,7 +145,8 @@ def main():
             "kernel_ms": {k: round(float(np.mean([x[k] for x in kms])), 3) for k in kms[0]},
             "per_read": {"bwt_extend": round(counters["extend"] / args.reads, 1), "occ_blocks": round(counters["blocks"] / args.reads, 1),
                          "sa_lookups": round(counters["sa"] / args.reads, 2), "lf_steps": round(counters["lf"] / args.reads, 1),
-                         "dp_cells": round(counters["cells"] / args.reads, 1)},
+                         "dp_cells": round(counters["cells"] / args.reads, 1),
+                         "dp_rows_1col": round(counters["dp_rows_1col"] / args.reads, 1), "dp_rows_ncol": round(counters["dp_rows_ncol"] / args.reads, 1)},
             "tail_us": {k: round(v / 100.0, 1) for k, v in counters.items() if k.endswith("_max")},
             "tail_counts": {"max_extends_per_read": counters.get("max_extends"), "max_seeds_per_read": counters.get("max_seeds"), "max_chains_per_read": counters.get("max_chains")},
             "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",

@@ -245,7 +245,7 @@ class Context:
         _check(lib().bwahip_batch_counters(self._h, buf, 24), "bwahip_batch_counters")
         names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells", "max_extends", "chain_build_max", "chain_sort_max", "chain_flt_max",
                  "chain_write_max", "max_seeds", "max_chains", "ext_max", "ext_dedup_max", "heavy_blocks", "heavy_intv", "heavy_reads",
-                 "_19", "_20", "_21", "_22", "_23"]
+                 "dp_rows_1col", "dp_rows_ncol", "dedup_sort1_max", "dedup_loop_max", "dedup_sort2_max"]
         return {k: int(buf[i]) for i, k in enumerate(names)}
 
     def kat_occ4(self, k):

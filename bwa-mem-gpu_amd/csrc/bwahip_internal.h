@@ -38,7 +38,18 @@ struct DevOpt {
 
 // Work counters kept in HBM, bumped once per wavefront at kernel exit (bwahip_batch_counters).
 enum { CNT_EXTEND = 0, CNT_BLOCKS, CNT_SA, CNT_LF, CNT_INTV, CNT_SEEDS, CNT_CELLS, CNT_MAX_EXT /* most bwt_extend calls of one read */,
-       CNT_HEAVY_BLOCKS = 16, CNT_HEAVY_INTV, CNT_HEAVY_READS, CNT_N = 24 };
+       CNT_HEAVY_BLOCKS = 16, CNT_HEAVY_INTV, CNT_HEAVY_READS, CNT_ROWS1 /* DP rows, 1 column per lane */, CNT_ROWSN /* DP rows, CPL columns per lane */, CNT_N = 24 };
+// The counters are kept in CNT_SLOTS copies (rows of CNT_N); a wavefront updates the row picked by its position in the
+// launch and the host folds the rows (sum, or max for the *_max entries).  One shared row made every wavefront's
+// end-of-work atomics queue up on the same L2 line: with a million wavefronts that alone cost tens of milliseconds.
+constexpr int CNT_SLOTS = 256;
+#define BWAHIP_MISC_BYTES ((size_t)CNT_SLOTS * CNT_N * 8 + 64)
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long *cnt_row(unsigned long long *base)
+{
+	return base + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (CNT_SLOTS - 1)) * CNT_N;
+}
+#endif
 
 // One interval / list entry in HBM: x[0], x[1], x[2], info  (bwtintv_t, bwt.h:62)
 struct __attribute__((aligned(32))) DevIntv { uint64_t x0, x1, x2, info; };

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 		}
 		a.chain_n[r] = -n_chn;                                  // pending marker
 		a.heavy_list[atomicAdd(a.heavy_count, 1)] = r;
-		if (a.counters) { atomicMax(&a.counters[8], t_1 - t_0); atomicMax(&a.counters[9], t_2 - t_1); atomicMax(&a.counters[12], (unsigned long long)S); atomicMax(&a.counters[13], (unsigned long long)n_chn); }
+		if (a.counters) { atomicMax(&cnt_row(a.counters)[8], t_1 - t_0); atomicMax(&cnt_row(a.counters)[9], t_2 - t_1); atomicMax(&cnt_row(a.counters)[12], (unsigned long long)S); atomicMax(&cnt_row(a.counters)[13], (unsigned long long)n_chn); }
 		return;
 	}
 	// NB: `first` and the kept list hold positions in the sorted array, as in the reference
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 	a.chain_n[r] = n_out;
 	a.kept_seeds[r] = tot;
 	if (a.counters) {                                           // phase maxima in 10 ns ticks (profiling aid)
-		atomicMax(&a.counters[8], t_1 - t_0); atomicMax(&a.counters[9], t_2 - t_1); atomicMax(&a.counters[10], t_3 - t_2);
-		atomicMax(&a.counters[11], wall_clock64() - t_3); atomicMax(&a.counters[12], (unsigned long long)S); atomicMax(&a.counters[13], (unsigned long long)n_chn);
+		atomicMax(&cnt_row(a.counters)[8], t_1 - t_0); atomicMax(&cnt_row(a.counters)[9], t_2 - t_1); atomicMax(&cnt_row(a.counters)[10], t_3 - t_2);
+		atomicMax(&cnt_row(a.counters)[11], wall_clock64() - t_3); atomicMax(&cnt_row(a.counters)[12], (unsigned long long)S); atomicMax(&cnt_row(a.counters)[13], (unsigned long long)n_chn);
 	}
 }
 
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64) void k_chain_flt(ChainLaunch a)
 			int so = ooff[k];
 			for (int s = cw[ci].head; s >= 0; s = nxt[s]) a.chain_seeds[sb + so++] = seeds[s];
 		}
-		if (l == 0 && a.counters) atomicMax(&a.counters[10], wall_clock64() - t_0);
+		if (l == 0 && a.counters) atomicMax(&cnt_row(a.counters)[10], wall_clock64() - t_0);
 		__syncthreads();
 	}
 }

@@ -32,16 +32,21 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_or(int v, i
 {
 	return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);   // lanes without a source keep `fill`
 }
-// inclusive prefix max over the 64 lanes (lane i gets max of lanes 0..i); ident = value below every input
-__device__ __forceinline__ int wscan_incl_max(int v, int ident)
+// inclusive prefix max over the 64 lanes (lane i gets max of lanes 0..i).  A lane without a DPP source keeps `old`,
+// and old = v makes that the identity of max, so every step is a single v_max_i32_dpp.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_self(int v)
+{
+	return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wscan_incl_max(int v, int /*ident*/)
 {
 	int t;
-	t = dpp_or<0x111, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:1
-	t = dpp_or<0x112, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:2
-	t = dpp_or<0x114, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:4
-	t = dpp_or<0x118, 0xf>(v, ident); v = v > t ? v : t;      // row_shr:8   -> scan inside each row of 16
-	t = dpp_or<0x142, 0xa>(v, ident); v = v > t ? v : t;      // row_bcast15 into rows 1,3
-	t = dpp_or<0x143, 0xc>(v, ident); v = v > t ? v : t;      // row_bcast31 into rows 2,3
+	t = dpp_self<0x111, 0xf>(v); v = v > t ? v : t;           // row_shr:1
+	t = dpp_self<0x112, 0xf>(v); v = v > t ? v : t;           // row_shr:2
+	t = dpp_self<0x114, 0xf>(v); v = v > t ? v : t;           // row_shr:4
+	t = dpp_self<0x118, 0xf>(v); v = v > t ? v : t;           // row_shr:8   -> scan inside each row of 16
+	t = dpp_self<0x142, 0xa>(v); v = v > t ? v : t;           // row_bcast15 into rows 1,3
+	t = dpp_self<0x143, 0xc>(v); v = v > t ? v : t;           // row_bcast31 into rows 2,3
 	return v;
 }
 __device__ __forceinline__ int wmax(int v) { return __builtin_amdgcn_readlane(wscan_incl_max(v, (int)0x80000000), 63); }
@@ -57,7 +62,10 @@ __device__ __forceinline__ int wscan_excl_max(int v, int ident)
 	return p;
 }
 
-struct Sw { const int8_t *mat; int o_del, e_del, o_ins, e_ins; };
+// per-wavefront work counters (all uniform; lane 0 adds them to the launch counters at the end)
+struct Work { unsigned long long cells; unsigned rows1, rowsN; };
+
+struct Sw { const int8_t *mat; int o_del, e_del, o_ins, e_ins, mx; };   // mx = largest entry of mat (ksw.c:399)
 
 // ---------------------------------------------------------------------------------------------------
 // ksw_extend2 (ksw.c:380).  q/t live in LDS and are read with a stride (+1 / -1) so the left extension
@@ -66,10 +74,15 @@ struct Sw { const int8_t *mat; int o_del, e_del, o_ins, e_ins; };
 template <int CPL>
 __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
                            int w, int end_bonus, int zdrop, int h0, int &qle, int &tle, int &gtle, int &gscore_, int &max_off_,
-                           unsigned long long &cells)
+                           Work &wk)
 {
 	const int l = lane(), j0 = l * CPL;
-	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
+	// every argument is wavefront-uniform, but it reaches here through per-lane loads: tell the compiler, so that the
+	// band bookkeeping and all control flow of the row loop run on the scalar unit
+	qlen = __builtin_amdgcn_readfirstlane(qlen); tlen = __builtin_amdgcn_readfirstlane(tlen); w = __builtin_amdgcn_readfirstlane(w);
+	end_bonus = __builtin_amdgcn_readfirstlane(end_bonus); zdrop = __builtin_amdgcn_readfirstlane(zdrop); h0 = __builtin_amdgcn_readfirstlane(h0);
+	const int oe_del = __builtin_amdgcn_readfirstlane(sw.o_del + sw.e_del), oe_ins = __builtin_amdgcn_readfirstlane(sw.o_ins + sw.e_ins);
+	const int e_del = __builtin_amdgcn_readfirstlane(sw.e_del), e_ins = __builtin_amdgcn_readfirstlane(sw.e_ins);
 	int qv[CPL], Hs[CPL], E[CPL];
 	// first row (ksw.c:396-397) and the query codes of this lane's columns
 	const int h1st = h0 > oe_ins ? h0 - oe_ins : 0;
@@ -84,8 +97,7 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 		Hs[c] = v; E[c] = 0;
 	}
 	// clamp the band (ksw.c:399-407)
-	int mx = 0;
-	for (int i = 0; i < 25; ++i) mx = mx > sw.mat[i] ? mx : sw.mat[i];
+	const int mx = sw.mx;
 	int max_ins = (int)((double)(qlen * mx + end_bonus - sw.o_ins) / e_ins + 1.);
 	max_ins = max_ins > 1 ? max_ins : 1;
 	w = w < max_ins ? w : max_ins;
@@ -114,7 +126,10 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 		if (end > qlen) end = qlen;
 		int h1 = 0;
 		if (beg == 0) { h1 = h0 - (sw.o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
-		cells += (end > beg && l == 0) ? (unsigned long long)(end - beg) : 0ull;
+		wk.cells += end > beg ? (unsigned)(end - beg) : 0u;          // wavefront-uniform; lane 0 reports it
+#ifndef NO_ROWS
+		if (CPL == 1) ++wk.rows1; else ++wk.rowsN;
+#endif
 		int M[CPL], u[CPL], P = NEG;
 #pragma unroll
 		for (int c = 0; c < CPL; ++c) {
@@ -158,10 +173,9 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 		key = wmax(key);
 		const int m = key < 0 ? 0 : key >> 10, mj = key < 0 ? -1 : key & 1023;
 		if (end == qlen) {                                        // ksw.c:450-453 (j == qlen after the loop)
-			int hend = 0;
+			int hend = 0;                                           // eh[end].h = H(i, qlen-1): column `end` sits in lane end / CPL
 #pragma unroll
-			for (int c = 0; c < CPL; ++c) if (j0 + c == end) hend = Hs[c];   // eh[end].h = H(i, qlen-1)
-			hend = wmax(hend);
+			for (int c = 0; c < CPL; ++c) if (end % CPL == c) hend = __builtin_amdgcn_readlane(Hs[c], end / CPL);
 			if (end == beg) hend = h1;
 			best_ie = gscore > hend ? best_ie : i;
 			gscore = gscore > hend ? gscore : hend;
@@ -201,7 +215,7 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 // ---------------------------------------------------------------------------------------------------
 template <int CPL>
 __device__ int wave_global_score(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w,
-                                 unsigned long long &cells)
+                                 Work &wk)
 {
 	const int l = lane(), j0 = l * CPL;
 	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
@@ -217,7 +231,10 @@ __device__ int wave_global_score(const Sw &sw, const uint8_t *q, int qs, int qle
 		const int tb = t[i * ts];
 		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1 = beg == 0 ? -(sw.o_del + e_del * (i + 1)) : NEG;
-		cells += (end > beg && l == 0) ? (unsigned long long)(end - beg) : 0ull;
+		wk.cells += end > beg ? (unsigned)(end - beg) : 0u;          // wavefront-uniform; lane 0 reports it
+#ifndef NO_ROWS
+		if (CPL == 1) ++wk.rows1; else ++wk.rowsN;
+#endif
 		int M[CPL], u[CPL], P = LOW;
 #pragma unroll
 		for (int c = 0; c < CPL; ++c) {
@@ -410,7 +427,7 @@ __device__ __forceinline__ bool chain_window(const DevIndex &ix, const DevOpt &o
 template <int CPL>
 __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, const uint8_t *s_q, const uint8_t *s_t, int l_query,
                                               int64_t rmax0, int tl_all, const DevSeed s, const DevChain &ch, const DevSeed *seeds, int n,
-                                              int l, unsigned long long &cells)
+                                              int l, Work &wk)
 {
 	DevReg reg;
 	reg.rb = reg.re = 0; reg.frac_rep = 0; reg.qb = reg.qe = 0; reg.sub = reg.csub = reg.sub_n = 0; reg.seedcov = 0;
@@ -425,9 +442,9 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 			aw0 = opt.w << i;
 			// a flank of at most 63 bases fits one column per lane: less than half the instructions per row
 			reg.score = s.qbeg < 64 ? wave_extend<1>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, cells)
+			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, wk)
 			                        : wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                           s.len * opt.a, qle, tle, gtle, gscore, max_off, cells);
+			                                           s.len * opt.a, qle, tle, gtle, gscore, max_off, wk);
 			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
@@ -440,9 +457,9 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 			const int prev = reg.score;
 			aw1 = opt.w << i;
 			reg.score = l_query - qe < 64 ? wave_extend<1>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                               qle, tle, gtle, gscore, max_off, cells)
+			                                               qle, tle, gtle, gscore, max_off, wk)
 			                              : wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                                 qle, tle, gtle, gscore, max_off, cells);
+			                                                 qle, tle, gtle, gscore, max_off, wk);
 			if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
@@ -476,7 +493,8 @@ __global__ __launch_bounds__(64) void k_extend_spec(ExtLaunch a)
 	const DevIndex &ix = a.ix;
 	Sw sw; sw.mat = s_mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins;
 	if (l < 25) s_mat[l] = opt.mat[l];
-	unsigned long long cells = 0;
+	sw.mx = wmax(l < 25 ? (int)opt.mat[l] : 0); if (sw.mx < 0) sw.mx = 0;
+	Work wk = { 0, 0, 0 };
 	const int n_items = *a.spec_n;
 	for (int it = (int)blockIdx.x; it < n_items; it += (int)gridDim.x) {
 		const int2 item = a.spec_items[it];
@@ -498,10 +516,10 @@ __global__ __launch_bounds__(64) void k_extend_spec(ExtLaunch a)
 		best = wmax64(best);
 		const DevSeed s = seeds[(int)(best & 0xffffffff)];
 		__syncthreads();
-		const DevReg reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, cells);
+		const DevReg reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, wk);
 		if (l == 0) a.spec_regs[sb + ci] = reg;
 	}
-	if (l == 0 && cells) atomicAdd(&a.counters[CNT_CELLS], cells);
+	if (l == 0 && wk.cells) { atomicAdd(&cnt_row(a.counters)[CNT_CELLS], wk.cells); atomicAdd(&cnt_row(a.counters)[CNT_ROWS1], (unsigned long long)wk.rows1); atomicAdd(&cnt_row(a.counters)[CNT_ROWSN], (unsigned long long)wk.rowsN); }
 }
 
 // work list of k_extend_spec: (read, chain) for every chain of a read with at least min_chains chains
@@ -534,10 +552,11 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	DevReg *av = a.regs + rb0;                                  // the read's region list (av of bwamem.c:639)
 	int *srt = a.srt + 2 * sb;                                  // [0..n): seed index in ascending (score,idx) order; [n..2n): skipped flag
 	int n_av = 0;
-	unsigned long long cells = 0;
+	Work wk = { 0, 0, 0 };
 	const unsigned long long t_0 = wall_clock64();
 	Sw sw; sw.mat = s_mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins;
 	if (l < 25) s_mat[l] = opt.mat[l];
+	sw.mx = wmax(l < 25 ? (int)opt.mat[l] : 0); if (sw.mx < 0) sw.mx = 0;
 	for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
 	__syncthreads();
 
@@ -608,7 +627,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 			// time by k_extend_spec (its result does not depend on the regions found so far, only the decision above does)
 			DevReg reg;
 			if (use_spec && k == n - 1) reg = a.spec_regs[sb + ci];
-			else reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, cells);
+			else reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, wk);
 			if (l == 0) av[n_av] = reg;
 			++n_av;
 			__threadfence_block();
@@ -625,11 +644,13 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	// in every lane (identical reads of av[]), stores are done by lane 0; the rare banded global alignment is
 	// collective.  The sort permutes an index array; the list is then gathered into that order.
 	int n = n_av;
+	unsigned long long t_s1 = t_1, t_lp = t_1;
 	if (n > 1) {
 		int *idx = srt;                                         // reuse: needs n ints (n <= number of seeds)
 		// sort by re
 		if (l == 0) { for (int i = 0; i < n; ++i) idx[i] = i; int bad = 0; rs_introsort(RegSort{av, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
 		__threadfence_block(); __syncthreads();
+		t_s1 = wall_clock64();
 		// gather into sorted order through the spare list (all lanes), then copy back
 		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
 		__threadfence_block(); __syncthreads();
@@ -695,8 +716,8 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 									gw = gw < w ? gw : w;
 									const int min_w = dl + 3;
 									gw = gw > min_w ? gw : min_w;
-									gsc = rev ? wave_global_score<CPL>(sw, s_q + p.qe - 1, -1, lq, s_t + rlen - 1, -1, rlen, gw, cells)
-									          : wave_global_score<CPL>(sw, s_q + q.qb, 1, lq, s_t, 1, rlen, gw, cells);
+									gsc = rev ? wave_global_score<CPL>(sw, s_q + p.qe - 1, -1, lq, s_t + rlen - 1, -1, rlen, gw, wk)
+									          : wave_global_score<CPL>(sw, s_q + q.qb, 1, lq, s_t, 1, rlen, gw, wk);
 								}
 								score = gsc;
 								const int q_s = (int)((double)(p.qe - q.qb) / ((p.qe - p.qb) + (q.qe - q.qb)) * (p.score + q.score) + .499);
@@ -731,6 +752,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 				__threadfence_block(); __syncthreads();
 			}
 		}
+		t_lp = wall_clock64();
 		// compact, sort by (score desc, rb, qb), drop identical hits (bwamem.c:481-495)
 		if (l == 0) {
 			int m = 0;
@@ -762,8 +784,9 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	}
 	if (l == 0) {
 		a.reg_n[r] = n;
-		if (cells) atomicAdd(&a.counters[CNT_CELLS], cells);
-		atomicMax(&a.counters[14], t_1 - t_0); atomicMax(&a.counters[15], wall_clock64() - t_1);
+		if (wk.cells) { atomicAdd(&cnt_row(a.counters)[CNT_CELLS], wk.cells); atomicAdd(&cnt_row(a.counters)[CNT_ROWS1], (unsigned long long)wk.rows1); atomicAdd(&cnt_row(a.counters)[CNT_ROWSN], (unsigned long long)wk.rowsN); }
+		atomicMax(&cnt_row(a.counters)[14], t_1 - t_0); atomicMax(&cnt_row(a.counters)[15], wall_clock64() - t_1);
+		atomicMax(&cnt_row(a.counters)[21], t_s1 - t_1); atomicMax(&cnt_row(a.counters)[22], t_lp - t_s1); atomicMax(&cnt_row(a.counters)[23], wall_clock64() - t_lp);
 	}
 }
 
@@ -793,9 +816,10 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
 	for (int i = l; i < tlen; i += 64) s_t[i] = t[toff[r] + i];
 	__syncthreads();
 	Sw sw; sw.mat = s_mat; sw.o_del = p[6]; sw.e_del = p[7]; sw.o_ins = p[8]; sw.e_ins = p[9];
+	sw.mx = wmax(l < 25 ? (int)opt.mat[l] : 0); if (sw.mx < 0) sw.mx = 0;
 	int qle, tle, gtle, gscore, max_off;
-	unsigned long long cells = 0;
-	int sc = wave_extend<11>(sw, s_q, 1, qlen, s_t, 1, tlen, p[2], p[5], p[4], p[3], qle, tle, gtle, gscore, max_off, cells);
+	Work wk = { 0, 0, 0 };
+	int sc = wave_extend<11>(sw, s_q, 1, qlen, s_t, 1, tlen, p[2], p[5], p[4], p[3], qle, tle, gtle, gscore, max_off, wk);
 	if (l == 0) { int *o = out6 + 6 * r; o[0] = sc; o[1] = qle; o[2] = tle; o[3] = gtle; o[4] = gscore; o[5] = max_off; }
 }
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_seed_walk(SeedLaunch a, long long total
 	}
 	unsigned long long lf = n_lf, sa = n_sa;
 	for (int m = 32; m; m >>= 1) { lf += __shfl_xor(lf, m); sa += __shfl_xor(sa, m); }
-	if (lane_id() == 0 && sa) { atomicAdd(&a.counters[CNT_SA], sa); atomicAdd(&a.counters[CNT_LF], lf); atomicAdd(&a.counters[CNT_SEEDS], sa); }
+	if (lane_id() == 0 && sa) { atomicAdd(&cnt_row(a.counters)[CNT_SA], sa); atomicAdd(&cnt_row(a.counters)[CNT_LF], lf); atomicAdd(&cnt_row(a.counters)[CNT_SEEDS], sa); }
 }
 
 // K2c -- contig id of every seed (bns_intv2rid, bntseq.c:370, as called at bwamem.c:293)

@@ -109,7 +109,7 @@ __device__ __forceinline__ int wave_finish_read(const SmemLaunch &a, const DevIn
 		a.out_n[rd] = n_emit;                                // > cap tells the host to re-run with more room
 		a.l_rep[rd] = n_ext;                                 // diagnostic: bwt_extend calls this read needed
 		a.seed_cnt[rd] = n_emit > cap ? 0 : n_seed;
-		if ((unsigned long long)n_ext > a.counters[CNT_MAX_EXT]) atomicMax(&a.counters[CNT_MAX_EXT], (unsigned long long)n_ext);
+		if ((unsigned long long)n_ext > cnt_row(a.counters)[CNT_MAX_EXT]) atomicMax(&cnt_row(a.counters)[CNT_MAX_EXT], (unsigned long long)n_ext);
 	}
 	return n;
 }
@@ -312,10 +312,13 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 			}
 		}
 	}
-	if (gl == 0 && (n_ext | n_out)) {
-		atomicAdd(&a.counters[CNT_EXTEND], (unsigned long long)n_ext);
-		atomicAdd(&a.counters[CNT_BLOCKS], (unsigned long long)n_blk);
-		atomicAdd(&a.counters[CNT_INTV], (unsigned long long)n_out);
+	{                                                        // one set of counter updates per wavefront
+		unsigned long long e = gl == 0 ? n_ext : 0, b = gl == 0 ? n_blk : 0, o = gl == 0 ? n_out : 0;
+		for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); o += __shfl_xor(o, m); }
+		if (lane == 0 && (e | o)) {
+			unsigned long long *cnt = cnt_row(a.counters);
+			atomicAdd(&cnt[CNT_EXTEND], e); atomicAdd(&cnt[CNT_BLOCKS], b); atomicAdd(&cnt[CNT_INTV], o);
+		}
 	}
 #undef PREV_AT
 #undef FWD_PUSH
@@ -501,8 +504,8 @@ __global__ __launch_bounds__(256) void k_smem_heavy(SmemLaunch a)
 	unsigned long long e = r.n_ext, b = r.n_blk;
 	for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); }
 	if (lane == 0 && (e | n_out)) {
-		atomicAdd(&a.counters[CNT_EXTEND], e); atomicAdd(&a.counters[CNT_BLOCKS], b); atomicAdd(&a.counters[CNT_INTV], (unsigned long long)n_out);
-		atomicAdd(&a.counters[CNT_HEAVY_BLOCKS], b); atomicAdd(&a.counters[CNT_HEAVY_INTV], (unsigned long long)n_out);
+		atomicAdd(&cnt_row(a.counters)[CNT_EXTEND], e); atomicAdd(&cnt_row(a.counters)[CNT_BLOCKS], b); atomicAdd(&cnt_row(a.counters)[CNT_INTV], (unsigned long long)n_out);
+		atomicAdd(&cnt_row(a.counters)[CNT_HEAVY_BLOCKS], b); atomicAdd(&cnt_row(a.counters)[CNT_HEAVY_INTV], (unsigned long long)n_out);
 	}
 }
 

@@ -109,7 +109,7 @@ struct bwahip_ctx {
 	int64_t total_bases = 0;
 	DevBuf d_seq, d_off, d_seq4, d_smem_heavy;
 	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
-	DevBuf d_misc;                       // [0..15] counters (u64), then queue (u32), err (i32)
+	DevBuf d_misc;                       // CNT_SLOTS rows of CNT_N counters (u64), then queue (4 x u32), err (i32)
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
@@ -189,8 +189,8 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 	std::vector<DevAnn> anns(bns->n_seqs);
 	for (int i = 0; i < bns->n_seqs; ++i) anns[i] = { bns->anns[i].offset, bns->anns[i].len, bns->anns[i].is_alt };
 	if ((rc = upload(c->d_anns, anns.data(), anns.size() * sizeof(DevAnn), c->stream))) return rc;
-	if ((rc = c->d_misc.ensure(1024))) return rc;
-	HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 1024, c->stream));
+	if ((rc = c->d_misc.ensure(BWAHIP_MISC_BYTES))) return rc;
+	HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, BWAHIP_MISC_BYTES, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	DevIndex &ix = c->ix;
 	memset(&ix, 0, sizeof ix);
@@ -357,7 +357,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	DevOpt dopt = make_dev_opt(opt);
 	if (c->ix.seq_len >= (1ull << 38) || c->max_len >= (1 << 14)) return BWAHIP_EINVAL;   // k_smem packs list entries as 3 x 38 + 14 bits
 	unsigned long long *counters = c->d_misc.as<unsigned long long>();
-	unsigned int *queue = (unsigned int*)(counters + CNT_N);
+	unsigned int *queue = (unsigned int*)(counters + (size_t)CNT_SLOTS * CNT_N);
 	int *err = (int*)(queue + 4);
 	int rc;
 	for (int attempt = 0; attempt < 8; ++attempt) {
@@ -368,7 +368,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = c->d_intv_n.ensure((size_t)n * 4)) || (rc = c->d_seed_cnt.ensure((size_t)n * 4)) || (rc = c->d_lrep.ensure((size_t)n * 4))) return rc;
 		if ((rc = c->d_seed_base.ensure((size_t)(n + 1) * 8))) return rc;
 		if ((rc = c->d_scratch.ensure((size_t)groups * ((size_t)lcap * 16 + (size_t)cap * 32)))) return rc;
-		HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 1024, c->stream));
+		HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, BWAHIP_MISC_BYTES, c->stream));
 		SmemLaunch sl;
 		memset(&sl, 0, sizeof sl);
 		sl.ix = c->ix; sl.opt = dopt; sl.n_reads = n; sl.seq = c->d_seq.as<uint8_t>(); sl.off = c->d_off.as<int64_t>();
@@ -515,8 +515,15 @@ int bwahip_batch_counters(bwahip_ctx *c, uint64_t *counters, int n)
 {
 	if (!c || !counters || n < 0) return BWAHIP_EINVAL;
 	HIP_TRY(hipSetDevice(c->device));
-	uint64_t h[CNT_N];
-	HIP_TRY(hipMemcpy(h, c->d_misc.p, sizeof h, hipMemcpyDeviceToHost));
+	std::vector<uint64_t> rows((size_t)CNT_SLOTS * CNT_N);
+	HIP_TRY(hipMemcpy(rows.data(), c->d_misc.p, rows.size() * 8, hipMemcpyDeviceToHost));
+	uint64_t h[CNT_N] = { 0 };
+	for (int s = 0; s < CNT_SLOTS; ++s)
+		for (int i = 0; i < CNT_N; ++i) {
+			const uint64_t v = rows[(size_t)s * CNT_N + i];
+			const bool is_max = i == CNT_MAX_EXT || (i >= 8 && i <= 15) || (i >= 21 && i <= 23);
+			h[i] = is_max ? std::max(h[i], v) : h[i] + v;
+		}
 	for (int i = 0; i < n; ++i) counters[i] = i < CNT_N ? h[i] : 0;
 	return 0;
 }
