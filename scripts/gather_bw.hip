@@ -36,8 +36,25 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *tab, uint64_t nblk,
 	if (acc == 0x1234567) atomicAdd(sink, acc);
 }
 
+__global__ __launch_bounds__(256) void k_copy(const uint4 *src, uint4 *dst, size_t n)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// streaming copy of `bytes` (read + write counted): the bandwidth ceiling a coalesced kernel sees
+static double run_copy(const uint4 *src, uint4 *dst, size_t bytes)
+{
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL(k_copy, dim3(256 * 32), dim3(256), 0, 0, src, dst, bytes / 16);
+	hipEventRecord(e0, 0);
+	for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_copy, dim3(256 * 32), dim3(256), 0, 0, src, dst, bytes / 16);
+	hipEventRecord(e1, 0); hipEventSynchronize(e1);
+	float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+	return 4.0 * 2.0 * bytes / ms / 1e6;
+}
+
 template <int K, int ST>
-static void run(const uint4 *tab, uint64_t nblk, int waves_per_cu, int steps, uint4 *scratch, uint64_t per_lane, unsigned long long *sink, const char *what)
+static double run(const uint4 *tab, uint64_t nblk, int waves_per_cu, int steps, uint4 *scratch, uint64_t per_lane, unsigned long long *sink, const char *what)
 {
 	int blocks = 256 * waves_per_cu / 4;
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -47,9 +64,10 @@ static void run(const uint4 *tab, uint64_t nblk, int waves_per_cu, int steps, ui
 	hipEventRecord(e1, 0); hipEventSynchronize(e1);
 	float ms = 0; hipEventElapsedTime(&ms, e0, e1);
 	double lines = (double)blocks * 256 * K * steps;
-	printf("%-28s table %6.0f MB  waves/CU %2d  K %d  store %d : %8.3f ms  %7.2f G gathers/s  %7.1f GB/s (64 B each)\n", what,
-	       nblk * 64 / 1e6, waves_per_cu, K, ST, ms, lines / ms / 1e6, lines * 64 / ms / 1e6);
+	if (what) printf("%-28s table %6.0f MB  waves/CU %2d  K %d  store %d : %8.3f ms  %7.2f G gathers/s  %7.1f GB/s (64 B each)\n", what,
+	                 nblk * 64 / 1e6, waves_per_cu, K, ST, ms, lines / ms / 1e6, lines * 64 / ms / 1e6);
 	fflush(stdout);
+	return lines * 64 / ms / 1e6;
 }
 
 int main(int argc, char **argv)
@@ -61,6 +79,12 @@ int main(int argc, char **argv)
 	const uint64_t per_lane = 256;                         // 4 KB of scratch per lane
 	hipMalloc(&scratch, (size_t)256 * 32 * 64 * per_lane * 16);
 	hipMemset(tab, 0x5a, max_bytes);
+	if (argc > 1 && argv[1][0] == 'q') {                     // quick mode for bench.py: one JSON line with the two measured ceilings
+		const double cp = run_copy(tab, tab + (2ull << 30) / 16, 2ull << 30);
+		const double ga = run<2, 0>(tab, 3072ull * (1ull << 20) / 64, 16, 400, scratch, per_lane, sink, nullptr);
+		printf("{\"stream_copy_GBps\": %.1f, \"gather64_GBps\": %.1f, \"gather_table_MB\": 3221}\n", cp, ga);
+		return 0;
+	}
 	if (argc > 1) {                                          // calibration run for the FETCH_SIZE counter: known bytes = gathers x 64
 		run<1, 0>(tab, 3072ull * (1ull << 20) / 64, 16, 400, scratch, per_lane, sink, "calibration: dependent gather");
 		printf("known bytes of the timed dispatch: %.0f (and a quarter of that for the warm-up dispatch)\n", 256.0 * 16 * 64 * 400 * 64);
@@ -75,5 +99,6 @@ int main(int argc, char **argv)
 		run<2, 1>(tab, nblk, 16, 400, scratch, per_lane, sink, "2 gathers + 16 B store");
 		run<2, 2>(tab, nblk, 16, 400, scratch, per_lane, sink, "2 gathers + 32 B store");
 	}
+	printf("streaming copy (2 GiB, read + write): %.1f GB/s\n", run_copy(tab, tab + (2ull << 30) / 16, 2ull << 30));
 	return 0;
 }
