@@ -153,6 +153,15 @@ def main():
                          "frac": round(achieved / 8000.0, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k1, 3)},
         }
+        # HBM traffic of the same kernel from the committed PMC pass of this very command (counters cannot be read from inside
+        # the process); only quoted when the workload string matches
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == out["config"]["workload"]:
+                out["roofline"]["traffic"] = int(pt["fetch_bytes_per_launch"] + pt["write_bytes_per_launch"])
+                out["roofline"]["traffic_source"] = pt["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         ceil = measured_ceilings() if world == 1 else None
         if ceil:
             # what this very device sustains for the kernel's access pattern (dependent random 64-byte gathers, one lane per
