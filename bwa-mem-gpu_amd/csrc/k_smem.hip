@@ -44,17 +44,19 @@ __device__ __forceinline__ void get(const DevIntv *p, uint64_t &x0, uint64_t &x1
 __device__ __forceinline__ uint64_t get_info(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].y; }
 __device__ __forceinline__ uint64_t get_x2(const DevIntv *p) { return reinterpret_cast<const ulonglong2*>(p)[1].x; }
 
-// list entry = (x0, x1, x2 : 38 bits each, query end : 14 bits); runtime.hip refuses indexes >= 2^38 positions
+// list entry = (x0, x1, x2 : 38 bits each, query end : 14 bits) = 16 bytes; runtime.hip refuses indexes >= 2^38 positions.
+// Words 0-2 hold the low 32 bits of x0/x1/x2, word 3 the three 6-bit tops and the end: only 32-bit shifts to pack/unpack.
 __device__ __forceinline__ uint4 pack_entry(uint64_t x0, uint64_t x1, uint64_t x2, uint32_t end)
 {
-	uint64_t lo = x0 | x1 << 38, hi = x1 >> 26 | x2 << 12 | (uint64_t)end << 50;
-	return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+	const uint32_t h0 = (uint32_t)(x0 >> 32), h1 = (uint32_t)(x1 >> 32), h2 = (uint32_t)(x2 >> 32);
+	return make_uint4((uint32_t)x0, (uint32_t)x1, (uint32_t)x2, h0 | h1 << 6 | h2 << 12 | end << 18);
 }
 __device__ __forceinline__ void unpack_entry(uint4 v, uint64_t &x0, uint64_t &x1, uint64_t &x2, uint64_t &end)
 {
-	uint64_t lo = (uint64_t)v.y << 32 | v.x, hi = (uint64_t)v.w << 32 | v.z;
-	const uint64_t M = (1ull << 38) - 1;
-	x0 = lo & M; x1 = (lo >> 38 | hi << 26) & M; x2 = hi >> 12 & M; end = hi >> 50;
+	x0 = (uint64_t)(v.w & 63) << 32 | v.x;
+	x1 = (uint64_t)(v.w >> 6 & 63) << 32 | v.y;
+	x2 = (uint64_t)(v.w >> 12 & 63) << 32 | v.z;
+	end = v.w >> 18;
 }
 
 // The read as 4-bit codes, 16 bases per 64-bit word (k_pack4 below); positions past the end hold 0xF.  A lane keeps
@@ -64,7 +66,8 @@ __device__ __forceinline__ int qbase(const uint64_t *row, int p, uint64_t &qw, i
 {
 	const int wi = p >> 4;
 	if (wi != qwi) { qw = row[wi]; qwi = wi; }
-	return (int)(qw >> ((p & 15) * 4)) & 15;
+	const uint32_t half = (p & 8) ? (uint32_t)(qw >> 32) : (uint32_t)qw;
+	return (int)(half >> ((p & 7) * 4)) & 15;
 }
 
 __global__ __launch_bounds__(256) void k_pack4(int n_reads, const uint8_t *seq, const int64_t *off, uint64_t *seq4, int stride)
@@ -114,6 +117,8 @@ __device__ __forceinline__ int wave_finish_read(const SmemLaunch &a, const DevIn
 	return n;
 }
 
+__device__ __forceinline__ int base_or_minus1(int b) { return b > 3 ? -1 : b; }
+
 // G = lanes per read: 8 (one quad per Occ block of an extend) or 4 (one quad does both blocks; 16 reads per wavefront)
 template <int G>
 __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 	uint64_t curr_last_x2 = 0, p_info = 0;
 	Bi ik = { 0, 0, 0 };
 	uint32_t ik_end = 0, last_push_end = 0;
-	int guard = 0;
+	int guard = 0, guard_max = 0;
 	bool exhausted = false;
 	unsigned int n_ext = 0, n_blk = 0, n_out = 0;
 
@@ -148,9 +153,13 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 #define LIST_PUT(P, X0, X1, X2, END) do { \
 		const int p_ = (P); const uint4 v_ = pack_entry((X0), (X1), (X2), (uint32_t)(END)); \
 		if (p_ < LL) { if (gl == 0) lrow[p_] = v_; } else spill[p_ - LL] = v_; } while (0)
+	// (the LDS read is unconditional so that the two sources stay a ds_read_b128 and a global_load_dwordx4: written as
+	// an if/else the compiler merges them into four flat_load_dword through a generic pointer)
 #define LIST_GET(P, X0, X1, X2, END) do { \
-		const int p_ = (P); uint4 v_; \
-		if (p_ < LL) v_ = lrow[p_]; else v_ = spill[p_ - LL]; \
+		const int p_ = (P); \
+		uint4 v_ = lrow[p_ < LL ? p_ : 0]; \
+		asm volatile("" : "+v"(v_.x), "+v"(v_.y), "+v"(v_.z), "+v"(v_.w)); \
+		if (p_ >= LL) v_ = spill[p_ - LL]; \
 		unpack_entry(v_, (X0), (X1), (X2), (END)); } while (0)
 	// backward phase: prev[jj] is read last-pushed-first (bwt.c:321-324 reverses curr) and stays that way in place
 #define PREV_AT(jj) (base + prev_n - 1 - (jj))
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 			if ((int)(uint32_t)(FWD_END) - (START) >= min_seed_len) EMIT((X0), (X1), (X2), (uint64_t)(START) << 32 | (uint32_t)(FWD_END)); \
 		} } while (0)
 #define QB(p) qbase(qrow, (p), qw, qwi)
-#define BASE_AT(p) (((p) < 0 || QB(p) > 3) ? -1 : QB(p))
+#define BASE_AT(p) ((p) < 0 ? -1 : base_or_minus1(QB(p)))
 	// bwt.c:289-303: start bwt_smem1a(X_, MI)
 #define START_SMEM(X_, MI) do { \
 		x = (X_); min_intv = (MI) < 1 ? 1 : (MI); \
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 			else {
 				rd = (int)t; qrow = a.seq4 + (size_t)t * a.seq4_stride; qwi = -1; len = (int)(a.off[t + 1] - a.off[t]);
 				out_n = 0; pass = 1; x = 0; guard = 0;
+				guard_max = a.heavy_mult > 0 ? a.heavy_mult * len + 64 : 64 * BWAHIP_MAX_READ_LEN;
 				st = len < min_seed_len ? ST_FINISH : ST_NEXT;   // bwamem.c:267
 			}
 		}
@@ -221,7 +231,8 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 					else st = ST_FINISH;
 				}
 			} else if (st == ST_FWD) {
-				if (i < len && QB(i) < 4) { need = true; is_back = 0; req = ik; cb = 3 - QB(i); }
+				const int bq = i < len ? QB(i) : 4;
+				if (bq < 4) { need = true; is_back = 0; req = ik; cb = 3 - bq; }
 				else {                                           // end of read / ambiguous base (bwt.c:316-320)
 					FWD_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
 					FWD_FINISH();
@@ -239,7 +250,8 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 					need = true; is_back = 1; cb = c;
 				}
 			} else if (st == ST_FWD3) {
-				if (i < len && QB(i) < 4) { need = true; is_back = 0; req = ik; cb = 3 - QB(i); }
+				const int bq = i < len ? QB(i) : 4;
+				if (bq < 4) { need = true; is_back = 0; req = ik; cb = 3 - bq; }
 				else { x = i < len ? i + 1 : len; st = ST_NEXT; }   // bwt.c:376-378
 			}
 		}
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 
 		// ---------------------------------------------------------------- consume the result
 		if (need) {
-			if (++guard > (a.heavy_mult > 0 ? a.heavy_mult * len + 64 : 64 * BWAHIP_MAX_READ_LEN)) {
+			if (++guard > guard_max) {
 				// a read deep inside a repeat: thousands of dependent steps would make it the critical path of the whole
 				// launch, so it is handed to k_smem_heavy, which runs each backward step across a wavefront
 				if (a.heavy_mult > 0) {
