@@ -98,6 +98,7 @@ struct SmemLaunch {
 	unsigned long long *counters;
 	int *err;
 	int groups_total;
+	int *worst_n;                               // largest interval count of a read whose list overflowed `cap`
 	int *heavy_list; unsigned int *heavy_n; int heavy_mult;   // reads handed to k_smem_heavy after heavy_mult*len extends (0: never)
 };
 int launch_smem(const SmemLaunch &a, int group_lanes, hipStream_t st);
@@ -132,8 +133,9 @@ struct ChainLaunch {
 	unsigned long long *counters;
 	int *flt;                                    // 8 ints per seed slot: per-position data for k_chain_flt
 	int *heavy_list, *heavy_count;               // reads whose overlap filter is deferred to k_chain_flt
+	int *big_list, *big_count; int big_min, big_max;   // reads with big_min < seeds <= big_max go to k_chain_big (nullptr: off)
 };
-int launch_chain(const ChainLaunch &a, hipStream_t st);
+int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_chain_flt(const ChainLaunch &a, hipStream_t st);
 
 struct ExtLaunch {

@@ -264,17 +264,22 @@ __device__ void write_chains(const ReadCtx &c, const DevIndex &ix, int n, const 
 	}
 }
 
-__global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
+// BIG = false: one read per lane.  Reads with big_min < seeds <= big_max are only listed; k_chain<true> then takes one
+// of them per workgroup (one working lane) with the B-tree nodes in LDS: the build is a chain of dependent node
+// visits, ~10 per seed, and a 2 000-seed read otherwise sets the duration of the whole launch through L2 latency.
+constexpr int BIG_NODES = 800;                               // 800 x 192 B = 150 KB of LDS; nodes <= seeds / 5 + a few
+
+template <bool BIG>
+__device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *lds_nodes)
 {
-	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= a.n_reads) return;
 	const int64_t sb = a.seed_base[r];
 	const int S = (int)(a.seed_base[r + 1] - sb), len = (int)(a.off[r + 1] - a.off[r]);
+	if (!BIG && a.big_list && S > a.big_min && S <= a.big_max) return;   // k_chain_big's (listed by k_chain_classify); it runs concurrently: touch nothing
 	ReadCtx c;
 	c.seeds = a.seeds + sb; c.n_seeds = S;
 	c.cw = reinterpret_cast<ChainW*>(a.cw_) + sb; c.nxt = a.nxt + sb; c.ord = a.ord + sb; c.wts = a.wts + sb; c.kept = a.kept + sb; c.first = a.first + sb;
 	c.keep_list = a.keep_list + sb;
-	c.nodes = reinterpret_cast<BtNode*>(a.nodes_) + (sb >> 2) + 4 * (int64_t)r;
+	c.nodes = BIG ? lds_nodes : reinterpret_cast<BtNode*>(a.nodes_) + (sb >> 2) + 4 * (int64_t)r;
 	c.stack = a.stack + 256 * (int64_t)r;
 	c.n_chains = 0; c.n_nodes = 0;
 	a.chain_n[r] = 0; a.kept_seeds[r] = 0;
@@ -400,6 +405,29 @@ __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 	}
 }
 
+__global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < a.n_reads) chain_read<false>(a, r, nullptr);
+}
+
+// the reads k_chain_big takes (so that it can run beside k_chain on a second stream)
+__global__ void k_chain_classify(ChainLaunch a)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.n_reads) return;
+	const int S = (int)(a.seed_base[r + 1] - a.seed_base[r]);
+	if (S > a.big_min && S <= a.big_max) a.big_list[atomicAdd(a.big_count, 1)] = r;
+}
+
+__global__ __launch_bounds__(64) void k_chain_big(ChainLaunch a)
+{
+	__shared__ BtNode nodes[BIG_NODES];
+	if (threadIdx.x != 0) return;
+	const int n_big = *a.big_count;
+	for (int h = blockIdx.x; h < n_big; h += gridDim.x) chain_read<true>(a, a.big_list[h], nodes);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_chain_flt: the pairwise overlap filter of mem_chain_flt (bwamem.c:350-392) for reads with many chains,
 // one read per wavefront.  For chain i (sequential, heavier first) the kept chains are tested 64 at a time;
@@ -511,9 +539,16 @@ int launch_chain_flt(const ChainLaunch &a, hipStream_t st)
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
-int launch_chain(const ChainLaunch &a, hipStream_t st)
+int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
 {
 	if (a.n_reads <= 0) return 0;
+	if (a.big_list) {                                        // many-seed reads: own kernel, concurrent with the rest
+		hipLaunchKernelGGL(k_chain_classify, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
+		if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess) return BWAHIP_ENODEV;
+		hipLaunchKernelGGL(k_chain_big, dim3(1024), dim3(64), 0, st2, a);
+		if (hipEventRecord(join, st2) != hipSuccess) return BWAHIP_ENODEV;
+	}
 	hipLaunchKernelGGL(k_chain, dim3((a.n_reads + 63) / 64), dim3(64), 0, st, a);
+	if (a.big_list && hipStreamWaitEvent(st, join, 0) != hipSuccess) return BWAHIP_ENODEV;
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

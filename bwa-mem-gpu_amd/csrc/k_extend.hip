@@ -65,6 +65,16 @@ __device__ __forceinline__ int wscan_excl_max(int v, int ident)
 // per-wavefront work counters (all uniform; lane 0 adds them to the launch counters at the end)
 struct Work { unsigned long long cells; unsigned rows1, rowsN; };
 
+// (int)((double)x / e + 1.) for integers x and e > 0, without leaving integer arithmetic: x / e is an integer plus r / e with
+// 0 <= r < e, so the double quotient never sits within rounding distance of an integer it is not equal to, and the
+// truncation toward zero is floor for x + e >= 0 and ceil below (ksw.c:402-407, bwamem.c:630-631).
+__device__ __forceinline__ int div_plus1_trunc(int x, int e)
+{
+	const int y = x + e;
+	if (e == 1) return y;
+	return y >= 0 ? y / e : -((-y) / e);
+}
+
 struct Sw { const int8_t *mat; int o_del, e_del, o_ins, e_ins, mx; };   // mx = largest entry of mat (ksw.c:399)
 
 // ---------------------------------------------------------------------------------------------------
@@ -98,10 +108,10 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 	}
 	// clamp the band (ksw.c:399-407)
 	const int mx = sw.mx;
-	int max_ins = (int)((double)(qlen * mx + end_bonus - sw.o_ins) / e_ins + 1.);
+	int max_ins = div_plus1_trunc(qlen * mx + end_bonus - sw.o_ins, e_ins);
 	max_ins = max_ins > 1 ? max_ins : 1;
 	w = w < max_ins ? w : max_ins;
-	int max_del = (int)((double)(qlen * mx + end_bonus - sw.o_del) / e_del + 1.);
+	int max_del = div_plus1_trunc(qlen * mx + end_bonus - sw.o_del, e_del);
 	max_del = max_del > 1 ? max_del : 1;
 	w = w < max_del ? w : max_del;
 	int best = h0, best_i = -1, best_j = -1, best_ie = -1, gscore = -1, max_off = 0;
@@ -309,8 +319,8 @@ __device__ __forceinline__ int ref_base(const DevIndex &ix, int64_t p)
 }
 __device__ __forceinline__ int cal_max_gap(const DevOpt &o, int qlen)           // bwamem.c:628
 {
-	int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
-	int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+	int l_del = div_plus1_trunc(qlen * o.a - o.o_del, o.e_del);
+	int l_ins = div_plus1_trunc(qlen * o.a - o.o_ins, o.e_ins);
 	int l = l_del > l_ins ? l_del : l_ins;
 	l = l > 1 ? l : 1;
 	return l < o.w << 1 ? l : o.w << 1;
@@ -707,8 +717,8 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 									for (int t = l; t < lq; t += 64) part += s_mat[s_t[t] * 5 + s_q[q.qb + t]];
 									gsc = wsum(part);
 								} else {
-									int max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-									int max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+									int max_ins = div_plus1_trunc(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins);
+									int max_del = div_plus1_trunc(((lq + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del);
 									int max_gap = max_ins > max_del ? max_ins : max_del;
 									max_gap = max_gap > 1 ? max_gap : 1;
 									int dl = rlen - lq; dl = dl < 0 ? -dl : dl;

@@ -112,6 +112,7 @@ __device__ __forceinline__ int wave_finish_read(const SmemLaunch &a, const DevIn
 		a.out_n[rd] = n_emit;                                // > cap tells the host to re-run with more room
 		a.l_rep[rd] = n_ext;                                 // diagnostic: bwt_extend calls this read needed
 		a.seed_cnt[rd] = n_emit > cap ? 0 : n_seed;
+		if (n_emit > cap) atomicMax(a.worst_n, n_emit);
 		if ((unsigned long long)n_ext > cnt_row(a.counters)[CNT_MAX_EXT]) atomicMax(&cnt_row(a.counters)[CNT_MAX_EXT], (unsigned long long)n_ext);
 	}
 	return n;

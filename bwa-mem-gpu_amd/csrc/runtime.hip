@@ -100,7 +100,8 @@ static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain"
 struct bwahip_ctx {
 	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr;     // stream2: kernels that run beside the main one (k_chain_big)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	HostIndex host;                      // host copy (owned when loaded from files)
 	DevIndex ix;
 	DevBuf d_bwt, d_sa, d_pac, d_anns;
@@ -113,7 +114,7 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big;
 	int intv_cap = 96;
 	int64_t total_seeds = 0, total_regs = 0;
 	hipEvent_t ev[16];
@@ -177,6 +178,8 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 {
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
 	int rc;
 	if (c->external_index) {             // adopt caller-owned device arrays (e.g. received over RCCL)
@@ -266,11 +269,14 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan };
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	bwahip_free_host_index(&c->host);
 	delete c;
 }
@@ -360,6 +366,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	unsigned int *queue = (unsigned int*)(counters + (size_t)CNT_SLOTS * CNT_N);
 	int *err = (int*)(queue + 4);
 	int rc;
+	if (getenv("BWAHIP_INTV_CAP")) c->intv_cap = std::max(2, atoi(getenv("BWAHIP_INTV_CAP")));   // tests: start small to exercise the re-run
 	for (int attempt = 0; attempt < 8; ++attempt) {
 		const int cap = c->intv_cap, lcap = c->max_len + 2;
 		const int G = getenv("BWAHIP_SMEM_LANES") ? atoi(getenv("BWAHIP_SMEM_LANES")) : 1;   // lanes per read in k_smem (1, 2, 4 or 8)
@@ -381,7 +388,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
 		const int heavy_mult = getenv("BWAHIP_HEAVY_MULT") ? atoi(getenv("BWAHIP_HEAVY_MULT")) : 10;   // x read length; 0 = never hand off
 		if ((rc = c->d_smem_heavy.ensure((size_t)n * 4))) return rc;
-		sl.heavy_list = c->d_smem_heavy.as<int>(); sl.heavy_n = queue + 1; sl.heavy_mult = heavy_mult;
+		sl.heavy_list = c->d_smem_heavy.as<int>(); sl.heavy_n = queue + 1; sl.heavy_mult = heavy_mult; sl.worst_n = (int*)(queue + 2);
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
 		if ((rc = launch_smem(sl, G, c->stream))) return rc;
 		STAGE_LOG("k_smem");
@@ -392,9 +399,10 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = launch_scan(c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
 		// the number of seeds sizes the next buffers: one 8-byte read-back per batch
-		int64_t total = 0; int h_err = 0;
+		int64_t total = 0; int h_err = 0, h_worst = 0;
 		HIP_TRY(hipMemcpyAsync(&total, c->d_seed_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemcpyAsync(&h_worst, queue + 2, 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (h_err) { fprintf(stderr, "[bwahip] k_smem reported an internal inconsistency\n"); return BWAHIP_EINTERNAL; }
 		if (const char *dump_ext = getenv("BWAHIP_DUMP_EXT")) {   // diagnostic: per-read bwt_extend counts as int32
@@ -402,12 +410,8 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 			HIP_TRY(hipMemcpy(h_e.data(), c->d_lrep.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 			if (FILE *fp = fopen(dump_ext, "wb")) { fwrite(h_e.data(), 4, n, fp); fclose(fp); }
 		}
-		// interval-list overflow: the kernel stores the true count; re-run the batch with more room (GPU only, no CPU path)
-		std::vector<int> h_n(n);
-		HIP_TRY(hipMemcpy(h_n.data(), c->d_intv_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-		int worst = 0;
-		for (int i = 0; i < n; ++i) worst = std::max(worst, h_n[i]);
-		if (worst > cap) { c->intv_cap = worst + 16; continue; }
+		// interval-list overflow: the kernel reports the largest true count; re-run the batch with more room (GPU only, no CPU path)
+		if (h_worst > cap) { c->intv_cap = h_worst + 16; continue; }
 		c->total_seeds = total;
 		if ((rc = c->d_seeds.ensure((size_t)(total ? total : 1) * sizeof(DevSeed)))) return rc;
 		SeedLaunch se;
@@ -442,10 +446,16 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		cl.counters = counters;
 		if ((rc = c->d_flt.ensure(T * 32)) || (rc = c->d_heavy.ensure((size_t)(n + 4) * 4))) return rc;
 		cl.flt = c->d_flt.as<int>(); cl.heavy_list = c->d_heavy.as<int>() + 4; cl.heavy_count = c->d_heavy.as<int>();
+		const int big_min = getenv("BWAHIP_CHAIN_BIG_MIN") ? atoi(getenv("BWAHIP_CHAIN_BIG_MIN")) : 1024;   // seeds; < 0 = off
+		if (big_min >= 0) {
+			if ((rc = c->d_chain_big.ensure((size_t)(n + 4) * 4))) return rc;
+			HIP_TRY(hipMemsetAsync(c->d_chain_big.p, 0, 16, c->stream));
+			cl.big_list = c->d_chain_big.as<int>() + 4; cl.big_count = c->d_chain_big.as<int>(); cl.big_min = big_min; cl.big_max = 3200;   // 800 LDS nodes >= 0.24 x seeds (every node but the root holds >= 5 keys)
+		}
 		HIP_TRY(hipMemsetAsync(c->d_heavy.p, 0, 16, c->stream));
 		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }
 		if (timed) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-		if ((rc = launch_chain(cl, c->stream))) return rc;
+		if ((rc = launch_chain(cl, c->stream, c->stream2, c->ev_fork, c->ev_join))) return rc;
 		if ((rc = launch_chain_flt(cl, c->stream))) return rc;
 		STAGE_LOG("k_chain");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));

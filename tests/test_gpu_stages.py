@@ -99,6 +99,35 @@ def test_regions_with_forced_ahead_of_time_extension(ctx, small_index, tmp_path,
     common.assert_stage_equal(got, want, bw.STAGE_REGS, f"regions[spec_min={spec_min}]")
 
 
+def test_interval_list_overflow_is_rerun_on_the_gpu(ctx, small_index, tmp_path, monkeypatch):
+    """A per-read interval capacity that is too small must be detected by k_smem and the batch re-run with more room
+    (no CPU path): start with room for 3 intervals per read."""
+    monkeypatch.setenv("BWAHIP_INTV_CAP", "3")
+    fq, seqs = _reads(small_index, tmp_path, "ovf", 1500, 150, 20000, 3000, 500, 119, 30000)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_INTV, bw.STAGE_REGS]))
+    common.assert_stage_equal(got, want, bw.STAGE_INTV, "intervals[cap=3]")
+    common.assert_stage_equal(got, want, bw.STAGE_REGS, "regions[cap=3]")
+    assert max(len(g[bw.STAGE_INTV]) for g in got) > 3 * 4
+
+
+@pytest.mark.parametrize("big_min", [-1, 0, 8])
+def test_chains_with_forced_lds_btree(ctx, small_index, tmp_path, monkeypatch, big_min):
+    """k_chain_big (B-tree nodes in LDS, one read per workgroup) forced onto every read with more than big_min seeds
+    (0: all reads with seeds; -1: switched off): chains before and after filtering must not change."""
+    monkeypatch.setenv("BWAHIP_CHAIN_BIG_MIN", str(big_min))
+    fq, seqs = _reads(small_index, tmp_path, "big", 3000, 150, 20000, 3000, 500, 117, 30000)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_CHAIN, bw.STAGE_CHAIN_FLT, bw.STAGE_REGS]))
+    for g, w in zip(got, want):
+        g[bw.STAGE_CHAIN] = _mask_chain_prefilter(g[bw.STAGE_CHAIN])
+        w[bw.STAGE_CHAIN] = _mask_chain_prefilter(w[bw.STAGE_CHAIN])
+    for st, what in [(bw.STAGE_CHAIN, "chains"), (bw.STAGE_CHAIN_FLT, "filtered chains"), (bw.STAGE_REGS, "regions")]:
+        common.assert_stage_equal(got, want, st, f"{what}[big_min={big_min}]")
+
+
 def test_fm_known_answers_vs_oracle_lib(ctx, small_index):
     """Device Occ / SA / extend against the oracle's C functions on random rows."""
     import ctypes as C
