@@ -453,6 +453,8 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 			// a flank of at most 63 bases fits one column per lane: less than half the instructions per row
 			reg.score = s.qbeg < 64 ? wave_extend<1>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
 			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, wk)
+			          : (CPL > 2 && s.qbeg < 128) ? wave_extend<2>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
+			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, wk)
 			                        : wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
 			                                           s.len * opt.a, qle, tle, gtle, gscore, max_off, wk);
 			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -467,6 +469,8 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 			const int prev = reg.score;
 			aw1 = opt.w << i;
 			reg.score = l_query - qe < 64 ? wave_extend<1>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
+			                                               qle, tle, gtle, gscore, max_off, wk)
+			          : (CPL > 2 && l_query - qe < 128) ? wave_extend<2>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
 			                                               qle, tle, gtle, gscore, max_off, wk)
 			                              : wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
 			                                                 qle, tle, gtle, gscore, max_off, wk);
