@@ -327,12 +327,15 @@ __device__ __forceinline__ int cal_max_gap(const DevOpt &o, int qlen)           
 }
 
 // ---- comparators of bwamem.c:398-402 on an index array into the read's DevReg list; exact introsort ----
-struct RegSort { const DevReg *a; int mode; };                  // mode 0: by re (mem_ars2); 1: score desc, rb, qb (mem_ars)
+// The sort keys are copied out of the 80-byte records into a dense 16-byte array first (by all lanes): the sorts run on
+// one lane, and what they wait for is the latency of the key fetches.
+struct RegKey { int64_t k64; int score, qb; };               // mode 0: k64 = re; mode 1: k64 = rb
+struct RegSort { const RegKey *key; int mode; };              // mode 0: by re (mem_ars2); 1: score desc, rb, qb (mem_ars)
 __device__ __forceinline__ bool reg_lt(const RegSort s, int x, int y)
 {
-	const DevReg &p = s.a[x], &q = s.a[y];
-	if (s.mode == 0) return p.re < q.re;
-	return p.score > q.score || (p.score == q.score && (p.rb < q.rb || (p.rb == q.rb && p.qb < q.qb)));
+	const RegKey p = s.key[x], q = s.key[y];
+	if (s.mode == 0) return p.k64 < q.k64;
+	return p.score > q.score || (p.score == q.score && (p.k64 < q.k64 || (p.k64 == q.k64 && p.qb < q.qb)));
 }
 __device__ __forceinline__ void rs_insertion(const RegSort c, int *s, int *t)
 {
@@ -662,7 +665,10 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 	if (n > 1) {
 		int *idx = srt;                                         // reuse: needs n ints (n <= number of seeds)
 		// sort by re
-		if (l == 0) { for (int i = 0; i < n; ++i) idx[i] = i; int bad = 0; rs_introsort(RegSort{av, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
+		RegKey *keys = reinterpret_cast<RegKey*>(a.tmp_regs + rb0);   // the spare list is free until the gather below
+		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
+		__threadfence_block(); __syncthreads();
+		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
 		__threadfence_block(); __syncthreads();
 		t_s1 = wall_clock64();
 		// gather into sorted order through the spare list (all lanes), then copy back
@@ -768,30 +774,43 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 		}
 		t_lp = wall_clock64();
 		// compact, sort by (score desc, rb, qb), drop identical hits (bwamem.c:481-495)
-		if (l == 0) {
+		{                                                       // drop the excluded entries (qe == qb), order kept: ballot compaction
 			int m = 0;
-			for (int i = 0; i < n; ++i) if (av[i].qe > av[i].qb) { if (m != i) av[m] = av[i]; ++m; }
-			for (int i = 0; i < m; ++i) idx[i] = i;
-			int bad = 0; rs_introsort(RegSort{av, 1}, m, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad);
-			s_stk[0] = m;
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + l;
+				const bool keep = i < n && av[i].qe > av[i].qb;
+				const unsigned long long km = __ballot(keep);
+				if (keep) a.tmp_regs[rb0 + m + __popcll(km & ((1ull << l) - 1))] = av[i];
+				m += __popcll(km);
+			}
+			__threadfence_block(); __syncthreads();
+			n = m;
+			for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+			__threadfence_block(); __syncthreads();
 		}
+		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].rb; keys[i].score = av[i].score; keys[i].qb = av[i].qb; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		n = s_stk[0];
-		__syncthreads();
+		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad); }
+		__threadfence_block(); __syncthreads();
 		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
 		__threadfence_block(); __syncthreads();
 		for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
 		__threadfence_block(); __syncthreads();
-		if (l == 0) {
-			for (int i = 1; i < n; ++i)
-				if (av[i].score == av[i-1].score && av[i].rb == av[i-1].rb && av[i].qb == av[i-1].qb) av[i].qe = av[i].qb;
-			int m = n > 0 ? 1 : 0;
-			for (int i = 1; i < n; ++i) if (av[i].qe > av[i].qb) { if (m != i) av[m] = av[i]; ++m; }
-			s_stk[0] = m;
+		{                                                       // identical hits (same score, rb, qb as the predecessor) go; bwamem.c:488-494
+			int m = 0;
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + l;
+				bool keep = i < n;
+				if (i > 0 && i < n) keep = !(av[i].score == av[i-1].score && av[i].rb == av[i-1].rb && av[i].qb == av[i-1].qb);
+				const unsigned long long km = __ballot(keep);
+				if (keep) a.tmp_regs[rb0 + m + __popcll(km & ((1ull << l) - 1))] = av[i];
+				m += __popcll(km);
+			}
+			__threadfence_block(); __syncthreads();
+			n = m;
+			for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+			__threadfence_block(); __syncthreads();
 		}
-		__threadfence_block(); __syncthreads();
-		n = s_stk[0];
-		__syncthreads();
 	}
 	for (int i = l; i < n; i += 64) {                           // bwamem.c:1091-1095
 		if (av[i].rid >= 0 && ix.anns[av[i].rid].is_alt) av[i].is_alt = 1;
