@@ -128,7 +128,9 @@ def main():
         # algorithmic bytes of the BWT-search kernel per launch: 64 B per Occ block touched by
         # bwt_extend + the read bytes in + 32 B per interval out, counted by the kernel itself
         # (the few reads k_smem hands to k_smem_heavy are counted by that kernel and subtracted here)
-        alg_bytes = 64 * (counters["blocks"] - counters["heavy_blocks"]) + args.reads * args.read_len + 32 * (counters["intv"] - counters["heavy_intv"])
+        # (pass 3 runs in k_smem3; its blocks and intervals are counted by that kernel and subtracted too)
+        alg_bytes = (64 * (counters["blocks"] - counters["heavy_blocks"] - counters["pass3_blocks"]) + args.reads * args.read_len +
+                     32 * (counters["intv"] - counters["heavy_intv"] - counters["pass3_intv"]))
         achieved = alg_bytes / (k1 * 1e-3) / 1e9
         out = {
             "metric": "reads/s aligned (150 bp vs hg38-scale synthetic genome), hot path mem_align1_core on GPU",
@@ -139,7 +141,7 @@ def main():
                                    f"{args.genome_mbp} Mbp synthetic genome with repeat families (GRCh38 not available offline); "
                                    "BASELINE configs[1] shape",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
-                       "stages": ["k_smem", "k_seeds", "k_chain", "k_extend(+dedup/patch)"],
+                       "stages": ["k_smem(passes 1-2)+k_smem_heavy+k_smem3(pass 3)+k_intv_sort", "k_seeds", "k_chain", "k_extend_spec+k_extend(+dedup/patch)"],
                        "output": "mem_alnreg_v per read resident in HBM (== mem_align1_core)",
                        "index_build_s": round(t_index, 1), "index_broadcast_s": round(t_bcast, 2)},
             "kernel_ms": {k: round(float(np.mean([x[k] for x in kms])), 3) for k in kms[0]},

@@ -241,11 +241,12 @@ class Context:
         return {lib().bwahip_kernel_name(i).decode(): float(ms[i]) for i in range(nk)}
 
     def counters(self):
-        buf = (C.c_uint64 * 24)()
-        _check(lib().bwahip_batch_counters(self._h, buf, 24), "bwahip_batch_counters")
+        buf = (C.c_uint64 * 32)()
+        _check(lib().bwahip_batch_counters(self._h, buf, 32), "bwahip_batch_counters")
         names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells", "max_extends", "chain_build_max", "chain_sort_max", "chain_flt_max",
                  "chain_write_max", "max_seeds", "max_chains", "ext_max", "ext_dedup_max", "heavy_blocks", "heavy_intv", "heavy_reads",
-                 "dp_rows_1col", "dp_rows_ncol", "dedup_sort1_max", "dedup_loop_max", "dedup_sort2_max"]
+                 "dp_rows_1col", "dp_rows_ncol", "dedup_sort1_max", "dedup_loop_max", "dedup_sort2_max",
+                 "pass3_blocks", "pass3_intv", "_26", "_27", "_28", "_29", "_30", "_31"]
         return {k: int(buf[i]) for i, k in enumerate(names)}
 
     def kat_occ4(self, k):

@@ -38,7 +38,8 @@ struct DevOpt {
 
 // Work counters kept in HBM, bumped once per wavefront at kernel exit (bwahip_batch_counters).
 enum { CNT_EXTEND = 0, CNT_BLOCKS, CNT_SA, CNT_LF, CNT_INTV, CNT_SEEDS, CNT_CELLS, CNT_MAX_EXT /* most bwt_extend calls of one read */,
-       CNT_HEAVY_BLOCKS = 16, CNT_HEAVY_INTV, CNT_HEAVY_READS, CNT_ROWS1 /* DP rows, 1 column per lane */, CNT_ROWSN /* DP rows, CPL columns per lane */, CNT_N = 24 };
+       CNT_HEAVY_BLOCKS = 16, CNT_HEAVY_INTV, CNT_HEAVY_READS, CNT_ROWS1 /* DP rows, 1 column per lane */, CNT_ROWSN /* DP rows, CPL columns per lane */,
+       CNT_P3_BLOCKS = 24, CNT_P3_INTV, CNT_N = 32 };
 // The counters are kept in CNT_SLOTS copies (rows of CNT_N); a wavefront updates the row picked by its position in the
 // launch and the host folds the rows (sum, or max for the *_max entries).  One shared row made every wavefront's
 // end-of-work atomics queue up on the same L2 line: with a million wavefronts that alone cost tens of milliseconds.
@@ -90,10 +91,11 @@ struct SmemLaunch {
 	int n_reads; const uint8_t *seq; const int64_t *off;
 	uint64_t *seq4; int seq4_stride;            // reads as 4-bit codes, seq4_stride 64-bit words per read (k_pack4)
 	DevIntv *out; int *out_n; int cap;          // per read: out[read*cap .. ), out_n[read]
+	DevIntv *raw; int *raw_n;                   // the same, unsorted: filled by k_smem / k_smem_heavy / k_smem3, sorted into `out` by k_intv_sort
 	int *seed_cnt;                              // per read: number of SA look-ups chaining will do (bwamem.c:285-286)
 	float *frac_rep_lrep;                       // unused slot (kept for layout stability)
 	int *l_rep;                                 // per read: number of bwt_extend calls (diagnostic)
-	DevIntv *scratch; int lcap;                 // per group: lcap 16-byte list spill entries + cap unsorted intervals
+	DevIntv *scratch; int lcap;                 // per group: lcap 16-byte list spill entries
 	unsigned int *queue;                        // work-queue head
 	unsigned long long *counters;
 	int *err;
@@ -104,6 +106,8 @@ struct SmemLaunch {
 int launch_smem(const SmemLaunch &a, int group_lanes, hipStream_t st);
 int launch_pack4(const SmemLaunch &a, hipStream_t st);
 int launch_smem_heavy(const SmemLaunch &a, hipStream_t st);
+int launch_smem3(const SmemLaunch &a, hipStream_t st);
+int launch_intv_sort(const SmemLaunch &a, hipStream_t st);
 int smem_default_groups(int group_lanes);
 
 struct SeedLaunch {

@@ -11,8 +11,9 @@
 // Per-read state machine (states cite the code they restate):
 //   pass 1  bwamem.c:144-154   for x: bwt_smem1(x, min_intv=1)        FWD (bwt.c:304-320) then BWD (bwt.c:326-345)
 //   pass 2  bwamem.c:156-165   re-seed long, rare SMEMs from their middle with min_intv = occ+1
-//   pass 3  bwamem.c:167-182   bwt_seed_strategy1 (bwt.c:358): forward-only, stop at occ < max_mem_intv
-//   sort    bwamem.c:184       by info=(qbeg<<32|qend); entries with equal info are the same bi-interval
+//   pass 3  bwamem.c:167-182   bwt_seed_strategy1 (bwt.c:358): forward-only, stop at occ < max_mem_intv -- its own kernel,
+//                              k_smem3 (independent of passes 1-2; a lean loop instead of one more state in this machine)
+//   sort    bwamem.c:184       k_intv_sort: by info=(qbeg<<32|qend); entries with equal info are the same bi-interval
 //                              (same query substring), so any sort yields the reference's array
 // Lists prev/curr (bwt.c:293) are ONE in-place list of 16-byte packed entries per read: curr[k] (k <= j) overwrites
 // the already consumed prev[k], so the swap of bwt.c:340 is a change of (base, n).  Its first 9*G entries live
@@ -24,7 +25,7 @@
 
 namespace {
 
-enum : int { ST_IDLE = 0, ST_NEXT, ST_FWD, ST_BWD, ST_FWD3, ST_FINISH };
+enum : int { ST_IDLE = 0, ST_NEXT, ST_FWD, ST_BWD, ST_FINISH };
 
 __device__ __forceinline__ void put(DevIntv *p, uint64_t x0, uint64_t x1, uint64_t x2, uint64_t info)
 {
@@ -86,12 +87,13 @@ __global__ __launch_bounds__(256) void k_pack4(int n_reads, const uint8_t *seq, 
 	seq4[t] = v;
 }
 
-// Finish one read with the whole wavefront: sort its n_emit unsorted intervals U by info (bwamem.c:184; entries with equal
-// info are identical, so a rank sort gives the reference's array), write the list, its length and the number of SA
-// look-ups chaining will make (bwamem.c:285-286).  All arguments are wavefront-uniform.  Returns the number written.
-__device__ __forceinline__ int wave_finish_read(const SmemLaunch &a, const DevIntv *Us, int n_emit, int rd, int n_ext, int lane)
+// Sort one read's unsorted intervals (raw row, written by k_smem / k_smem_heavy / k_smem3) by info with the whole wavefront
+// (bwamem.c:184; entries with equal info are identical, so a rank sort gives the reference's array) and write the list,
+// its length and the number of SA look-ups chaining will make (bwamem.c:285-286).
+__device__ __forceinline__ void wave_sort_read(const SmemLaunch &a, int rd, int lane)
 {
-	const int cap = a.cap, n = n_emit < cap ? n_emit : cap;
+	const int cap = a.cap, n_emit = a.raw_n[rd], n = n_emit < cap ? n_emit : cap;
+	const DevIntv *Us = a.raw + (size_t)rd * cap;
 	DevIntv *dst = a.out + (size_t)rd * cap;
 	int n_seed = 0;
 	for (int t = lane; t < n; t += 64) {
@@ -110,12 +112,17 @@ __device__ __forceinline__ int wave_finish_read(const SmemLaunch &a, const DevIn
 	for (int m = 32; m; m >>= 1) n_seed += __shfl_xor(n_seed, m);
 	if (lane == 0) {
 		a.out_n[rd] = n_emit;                                // > cap tells the host to re-run with more room
-		a.l_rep[rd] = n_ext;                                 // diagnostic: bwt_extend calls this read needed
 		a.seed_cnt[rd] = n_emit > cap ? 0 : n_seed;
 		if (n_emit > cap) atomicMax(a.worst_n, n_emit);
-		if ((unsigned long long)n_ext > cnt_row(a.counters)[CNT_MAX_EXT]) atomicMax(&cnt_row(a.counters)[CNT_MAX_EXT], (unsigned long long)n_ext);
 	}
-	return n;
+}
+
+// end of passes 1-2 for one read (one lane): interval count so far, diagnostics
+__device__ __forceinline__ void finish_pass12(const SmemLaunch &a, int rd, int n_emit, int n_ext)
+{
+	a.raw_n[rd] = n_emit;
+	a.l_rep[rd] = n_ext;                                     // diagnostic: bwt_extend calls passes 1-2 of this read needed
+	if ((unsigned long long)n_ext > cnt_row(a.counters)[CNT_MAX_EXT]) atomicMax(&cnt_row(a.counters)[CNT_MAX_EXT], (unsigned long long)n_ext);
 }
 
 __device__ __forceinline__ int base_or_minus1(int b) { return b > 3 ? -1 : b; }
@@ -133,10 +140,8 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 	constexpr int LL = 9 * G;                                // list entries kept in LDS per read
 	__shared__ uint4 lds_list[(256 / G) * (LL + 1)];         // +1: rows start on different banks
 	uint4 *const lrow = lds_list + (threadIdx.x / G) * (LL + 1);
-	const size_t region_bytes = (size_t)lcap * 16 + (size_t)cap * 32;
-	char *const region = reinterpret_cast<char*>(a.scratch) + (size_t)group * region_bytes;
-	uint4 *const spill = reinterpret_cast<uint4*>(region);   // list entries LL.. (lcap of them)
-	DevIntv *const U = reinterpret_cast<DevIntv*>(region + (size_t)lcap * 16);   // unsorted accumulated intervals of the read
+	uint4 *const spill = reinterpret_cast<uint4*>(a.scratch) + (size_t)group * lcap;   // list entries LL.. (lcap of them)
+	DevIntv *U = a.raw;                                      // unsorted accumulated intervals of the current read (its raw row)
 
 	// ---- per-group state (identical in every lane of the group; plain scalars so it stays in registers) ----
 	int st = ST_IDLE, rd = -1, len = 0, pass = 0;
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 			if (G > 1) t = __shfl(t, lane & ~(G - 1));
 			if (t >= (unsigned)a.n_reads) exhausted = true;
 			else {
-				rd = (int)t; qrow = a.seq4 + (size_t)t * a.seq4_stride; qwi = -1; len = (int)(a.off[t + 1] - a.off[t]);
+				rd = (int)t; qrow = a.seq4 + (size_t)t * a.seq4_stride; qwi = -1; U = a.raw + (size_t)t * cap; len = (int)(a.off[t + 1] - a.off[t]);
 				out_n = 0; pass = 1; x = 0; guard = 0;
 				guard_max = a.heavy_mult > 0 ? a.heavy_mult * len + 64 : 64 * BWAHIP_MAX_READ_LEN;
 				st = len < min_seed_len ? ST_FINISH : ST_NEXT;   // bwamem.c:267
@@ -225,11 +230,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 						START_SMEM((b + e) >> 1, (int)x2 + 1);
 						started = true;
 					}
-					if (!started) { pass = 3; x = 0; if (a.opt.max_mem_intv <= 0) st = ST_FINISH; }
-				} else {
-					while (x < len && QB(x) > 3) ++x;             // bwamem.c:170,181
-					if (x < len) { set_intv(ix, QB(x), ik); i = x + 1; st = ST_FWD3; }
-					else st = ST_FINISH;
+					if (!started) st = ST_FINISH;                  // pass 3 is k_smem3's
 				}
 			} else if (st == ST_FWD) {
 				const int bq = i < len ? QB(i) : 4;
@@ -250,35 +251,18 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 					LIST_GET(PREV_AT(j), req.x0, req.x1, req.x2, p_info);
 					need = true; is_back = 1; cb = c;
 				}
-			} else if (st == ST_FWD3) {
-				const int bq = i < len ? QB(i) : 4;
-				if (bq < 4) { need = true; is_back = 0; req = ik; cb = 3 - bq; }
-				else { x = i < len ? i + 1 : len; st = ST_NEXT; }   // bwt.c:376-378
 			}
 		}
 
-		// ---------------------------------------------------------------- finished reads: the whole wavefront sorts each one
-		// (bwamem.c:184, by info) with a rank sort over 64 lanes and writes the read's interval list; doing this
-		// inside one lane would stall the other reads of the wavefront for O(n^2) steps
-		uint64_t fm = __ballot(st == ST_FINISH && gl == 0);
-		if (fm) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // U was written by the owner lanes, read by all below
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			while (fm) {
-				const int src = __ffsll((unsigned long long)fm) - 1;
-				fm &= fm - 1;
-				const int s_out = __shfl(out_n, src), s_rd = __shfl(rd, src), s_ext = __shfl(guard, src);
-				const DevIntv *Us = reinterpret_cast<const DevIntv*>(reinterpret_cast<const char*>(a.scratch) +
-				                                                     (size_t)(group - lane / G + src / G) * region_bytes + (size_t)lcap * 16);
-				const int n = wave_finish_read(a, Us, s_out, s_rd, s_ext, lane);
-				if (lane == src) n_out += n;
-				if ((lane & ~(G - 1)) == src) { st = ST_IDLE; rd = -1; }
-			}
+		// ---------------------------------------------------------------- passes 1-2 of a read are done
+		if (st == ST_FINISH) {
+			if (gl == 0) { finish_pass12(a, rd, out_n, guard); n_out += out_n < cap ? out_n : cap; }
+			st = ST_IDLE; rd = -1;
 		}
 
 		// ---------------------------------------------------------------- the one convergent bwt_extend
 		Bi o;
-		bool live = need && !(st == ST_FWD3 && ik.x2 == 0);     // an empty interval stays empty: no gather needed
+		const bool live = need;
 		int nb = G == 8 ? group8_extend_c(ix, req, is_back, cb, live, o) : G == 4 ? quad_extend_c(ix, req, is_back, cb, live, o) : G == 2 ? pair_extend_c(ix, req, is_back, cb, live, o)
 		                                                                        : lane_extend_c(ix, req, is_back, cb, live, o);
 		if (need && gl == 0) { ++n_ext; n_blk += nb; }
@@ -317,11 +301,6 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 						--i; j = 0; c = BASE_AT(i);
 					}
 				}
-			} else if (st == ST_FWD3) {                            // bwt.c:366-375
-				if (o.x2 < (uint64_t)a.opt.max_mem_intv && i - x >= min_seed_len) {
-					if (o.x2 > 0) EMIT(o.x0, o.x1, o.x2, (uint64_t)x << 32 | (uint32_t)(i + 1));   // bwamem.c:174
-					x = i + 1; st = ST_NEXT;
-				} else { ik = o; ++i; }
 			}
 		}
 	}
@@ -459,17 +438,15 @@ __global__ __launch_bounds__(256) void k_smem_heavy(SmemLaunch a)
 	__shared__ uint4 lists[4][BWAHIP_MAX_READ_LEN + 8];
 	const int lane = lane_id();
 	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
-	const DevIndex &ix = a.ix;
-	const size_t region_bytes = (size_t)a.lcap * 16 + (size_t)a.cap * 32;
 	HeavyRead r;
 	r.L = lists[threadIdx.x >> 6];
-	r.U = reinterpret_cast<DevIntv*>(reinterpret_cast<char*>(a.scratch) + (size_t)wave * region_bytes + (size_t)a.lcap * 16);
 	r.n_ext = r.n_blk = 0;
 	const unsigned n_heavy = *a.heavy_n;
 	unsigned n_out = 0;
 	for (unsigned h = (unsigned)wave; h < n_heavy; h += (unsigned)n_waves) {
 		const int rd = a.heavy_list[h];
 		r.qrow = a.seq4 + (size_t)rd * a.seq4_stride; r.qwi = -1; r.qw = 0;
+		r.U = a.raw + (size_t)rd * a.cap;
 		r.len = (int)(a.off[rd + 1] - a.off[rd]);
 		r.out_n = 0; r.ext = 0;
 		const int len = r.len;
@@ -488,31 +465,9 @@ __global__ __launch_bounds__(256) void k_smem_heavy(SmemLaunch a)
 				if (qbase(r.qrow, (b + e) >> 1, r.qw, r.qwi) > 3) continue;
 				heavy_smem1(a, r, lane, (b + e) >> 1, (int)x2 + 1);
 			}
-			if (a.opt.max_mem_intv > 0) {                    // pass 3 (bwamem.c:167-182, bwt.c:358-380)
-				for (int x = 0; x < len;) {
-					if (qbase(r.qrow, x, r.qw, r.qwi) > 3) { ++x; continue; }
-					Bi ik; set_intv(ix, qbase(r.qrow, x, r.qw, r.qwi), ik);
-					int i, nx = len;
-					for (i = x + 1; i < len; ++i) {
-						const int b = qbase(r.qrow, i, r.qw, r.qwi);
-						if (b > 3) { nx = i + 1; break; }
-						Bi o;
-						const bool live = ik.x2 != 0;
-						int nb = lane_extend_c(ix, ik, 0, 3 - b, live, o);
-						if (lane == 0) { ++r.n_ext; r.n_blk += nb; }
-						++r.ext;
-						if (o.x2 < (uint64_t)a.opt.max_mem_intv && i - x >= a.opt.min_seed_len) {
-							if (o.x2 > 0) heavy_emit(a, r, lane, o.x0, o.x1, o.x2, (uint64_t)x << 32 | (uint32_t)(i + 1));
-							nx = i + 1; break;
-						}
-						ik = o;
-					}
-					x = nx;
-				}
-			}
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		n_out += wave_finish_read(a, r.U, r.out_n, rd, r.ext, lane);
+		if (lane == 0) finish_pass12(a, rd, r.out_n, r.ext);   // pass 3 is k_smem3's
+		n_out += r.out_n < a.cap ? r.out_n : a.cap;
 	}
 	unsigned long long e = r.n_ext, b = r.n_blk;
 	for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); }
@@ -520,6 +475,76 @@ __global__ __launch_bounds__(256) void k_smem_heavy(SmemLaunch a)
 		atomicAdd(&cnt_row(a.counters)[CNT_EXTEND], e); atomicAdd(&cnt_row(a.counters)[CNT_BLOCKS], b); atomicAdd(&cnt_row(a.counters)[CNT_INTV], (unsigned long long)n_out);
 		atomicAdd(&cnt_row(a.counters)[CNT_HEAVY_BLOCKS], b); atomicAdd(&cnt_row(a.counters)[CNT_HEAVY_INTV], (unsigned long long)n_out);
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1c -- pass 3 of mem_collect_intv (bwamem.c:167-182): bwt_seed_strategy1 (bwt.c:358-380) from every position the
+// previous seed ended at: forward-only extension until the interval is smaller than max_mem_intv and at least
+// min_seed_len long.  Independent of passes 1-2 (it only appends to the same list), so it runs as its own lean loop:
+// one read per lane, one bwt_extend per iteration, nothing but the interval and two positions as state.
+__global__ __launch_bounds__(256) void k_smem3(SmemLaunch a)
+{
+	const DevIndex &ix = a.ix;
+	const long long n_lanes = (long long)gridDim.x * blockDim.x;
+	long long next = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int cap = a.cap, min_seed_len = a.opt.min_seed_len;
+	const uint64_t max_intv = (uint64_t)a.opt.max_mem_intv;
+	enum : int { P_IDLE = 0, P_SCAN, P_EXT };
+	int st = P_IDLE, rd = 0, len = 0, x = 0, i = 0, out_n = 0;
+	const uint64_t *qrow = nullptr; uint64_t qw = 0; int qwi = -1;
+	DevIntv *U = a.raw;
+	Bi ik = { 0, 0, 0 };
+	unsigned n_ext = 0, n_blk = 0, n_new = 0;
+	for (;;) {
+		if (st == P_IDLE && next < a.n_reads) {
+			rd = (int)next; next += n_lanes;
+			len = (int)(a.off[rd + 1] - a.off[rd]);
+			qrow = a.seq4 + (size_t)rd * a.seq4_stride; qwi = -1;
+			U = a.raw + (size_t)rd * cap; out_n = a.raw_n[rd];
+			x = 0;
+			if (len >= min_seed_len) st = P_SCAN;                // bwamem.c:267: shorter reads have no intervals at all
+		}
+		if (__ballot(st != P_IDLE) == 0) break;
+		bool need = false; int cb = 0;
+		for (int spin = 0; spin < 4096 && !need && st != P_IDLE; ++spin) {
+			if (st == P_SCAN) {
+				while (x < len && qbase(qrow, x, qw, qwi) > 3) ++x;   // bwamem.c:170,181
+				if (x < len) { set_intv(ix, qbase(qrow, x, qw, qwi), ik); i = x + 1; st = P_EXT; }
+				else { a.raw_n[rd] = out_n; st = P_IDLE; }
+			} else {
+				const int bq = i < len ? qbase(qrow, i, qw, qwi) : 4;
+				if (bq < 4) { need = true; cb = 3 - bq; }
+				else { x = i < len ? i + 1 : len; st = P_SCAN; }   // bwt.c:376-378
+			}
+		}
+		Bi o;
+		const bool live = need && ik.x2 != 0;                    // an empty interval stays empty: no gather needed
+		const int nb = lane_extend_c(ix, ik, 0, cb, live, o);
+		if (need) {
+			++n_ext; n_blk += nb;
+			if (o.x2 < max_intv && i - x >= min_seed_len) {       // bwt.c:366-375
+				if (o.x2 > 0) {                                  // bwamem.c:174
+					if (out_n < cap) put(U + out_n, o.x0, o.x1, o.x2, (uint64_t)x << 32 | (uint32_t)(i + 1));
+					++out_n; ++n_new;
+				}
+				x = i + 1; st = P_SCAN;
+			} else { ik = o; ++i; }
+		}
+	}
+	unsigned long long e = n_ext, b = n_blk, o = n_new;
+	for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); o += __shfl_xor(o, m); }
+	if (lane_id() == 0 && e) {
+		unsigned long long *cnt = cnt_row(a.counters);
+		atomicAdd(&cnt[CNT_EXTEND], e); atomicAdd(&cnt[CNT_BLOCKS], b); atomicAdd(&cnt[CNT_INTV], o);
+		atomicAdd(&cnt[CNT_P3_BLOCKS], b); atomicAdd(&cnt[CNT_P3_INTV], o);
+	}
+}
+
+// K1d -- one wavefront per read: sort the raw interval row by info (bwamem.c:184) into the output row
+__global__ __launch_bounds__(256) void k_intv_sort(SmemLaunch a)
+{
+	const int rd = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	if (rd < a.n_reads) wave_sort_read(a, rd, lane_id());
 }
 
 } // namespace
@@ -537,6 +562,22 @@ int launch_pack4(const SmemLaunch &a, hipStream_t st)
 {
 	const int64_t words = (int64_t)a.n_reads * a.seq4_stride;
 	hipLaunchKernelGGL(k_pack4, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, a.n_reads, a.seq, a.off, a.seq4, a.seq4_stride);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+int launch_smem3(const SmemLaunch &a, hipStream_t st)
+{
+	if (a.opt.max_mem_intv > 0) {
+		int blocks = (a.n_reads + 255) / 256;
+		if (blocks > 256 * 8) blocks = 256 * 8;                  // 8 waves per SIMD resident; lanes stride over the reads
+		hipLaunchKernelGGL(k_smem3, dim3(blocks), dim3(256), 0, st, a);
+	}
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+int launch_intv_sort(const SmemLaunch &a, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_intv_sort, dim3((a.n_reads + 3) / 4), dim3(256), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 

@@ -95,7 +95,7 @@ int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st)
 }
 } // namespace
 
-static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec" };
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec", "k_smem3", "k_intv_sort" };
 
 struct bwahip_ctx {
 	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
@@ -108,7 +108,7 @@ struct bwahip_ctx {
 	// batch state
 	int n_reads = 0, max_len = 0;
 	int64_t total_bases = 0;
-	DevBuf d_seq, d_off, d_seq4, d_smem_heavy;
+	DevBuf d_seq, d_off, d_seq4, d_smem_heavy, d_raw, d_raw_n;
 	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
 	DevBuf d_misc;                       // CNT_SLOTS rows of CNT_N counters (u64), then queue (4 x u32), err (i32)
 	// K3/K4 working set (sized from the seed count of the batch)
@@ -118,7 +118,7 @@ struct bwahip_ctx {
 	int intv_cap = 96;
 	int64_t total_seeds = 0, total_regs = 0;
 	hipEvent_t ev[16];
-	float last_ms[8];
+	float last_ms[12];
 };
 
 DevOpt make_dev_opt(const bwahip_opt_t *o)
@@ -265,7 +265,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
@@ -371,15 +371,16 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		const int cap = c->intv_cap, lcap = c->max_len + 2;
 		const int G = getenv("BWAHIP_SMEM_LANES") ? atoi(getenv("BWAHIP_SMEM_LANES")) : 1;   // lanes per read in k_smem (1, 2, 4 or 8)
 		const int groups = smem_default_groups(G);
-		if ((rc = c->d_intv.ensure((size_t)n * cap * sizeof(DevIntv)))) return rc;
+		if ((rc = c->d_intv.ensure((size_t)n * cap * sizeof(DevIntv))) || (rc = c->d_raw.ensure((size_t)n * cap * sizeof(DevIntv))) || (rc = c->d_raw_n.ensure((size_t)n * 4))) return rc;
 		if ((rc = c->d_intv_n.ensure((size_t)n * 4)) || (rc = c->d_seed_cnt.ensure((size_t)n * 4)) || (rc = c->d_lrep.ensure((size_t)n * 4))) return rc;
 		if ((rc = c->d_seed_base.ensure((size_t)(n + 1) * 8))) return rc;
-		if ((rc = c->d_scratch.ensure((size_t)groups * ((size_t)lcap * 16 + (size_t)cap * 32)))) return rc;
+		if ((rc = c->d_scratch.ensure((size_t)groups * (size_t)lcap * 16))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, BWAHIP_MISC_BYTES, c->stream));
 		SmemLaunch sl;
 		memset(&sl, 0, sizeof sl);
 		sl.ix = c->ix; sl.opt = dopt; sl.n_reads = n; sl.seq = c->d_seq.as<uint8_t>(); sl.off = c->d_off.as<int64_t>();
 		sl.out = c->d_intv.as<DevIntv>(); sl.out_n = c->d_intv_n.as<int>(); sl.cap = cap;
+		sl.raw = c->d_raw.as<DevIntv>(); sl.raw_n = c->d_raw_n.as<int>();
 		sl.seed_cnt = c->d_seed_cnt.as<int>(); sl.l_rep = c->d_lrep.as<int>();
 		sl.seq4_stride = (c->max_len + 15) / 16 + 1;            // +1: a word of 0xF past the longest read
 		if ((rc = c->d_seq4.ensure((size_t)n * sl.seq4_stride * 8))) return rc;
@@ -395,6 +396,12 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 		if (heavy_mult > 0 && (rc = launch_smem_heavy(sl, c->stream))) return rc;
 		STAGE_LOG("k_smem_heavy");
+		if (timed) HIP_TRY(hipEventRecord(c->ev[12], c->stream));
+		if ((rc = launch_smem3(sl, c->stream))) return rc;
+		STAGE_LOG("k_smem3");
+		if (timed) HIP_TRY(hipEventRecord(c->ev[13], c->stream));
+		if ((rc = launch_intv_sort(sl, c->stream))) return rc;
+		STAGE_LOG("k_intv_sort");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[10], c->stream));
 		if ((rc = launch_scan(c->d_seed_cnt.as<int>(), c->d_seed_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
@@ -500,7 +507,9 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if (timed) {
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[1], c->ev[10], c->ev[2]));
-			HIP_TRY(hipEventElapsedTime(&c->last_ms[6], c->ev[1], c->ev[10]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[6], c->ev[1], c->ev[12]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[8], c->ev[12], c->ev[13]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[9], c->ev[13], c->ev[10]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[6]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[4], c->ev[6], c->ev[7]));
@@ -531,7 +540,7 @@ int bwahip_batch_counters(bwahip_ctx *c, uint64_t *counters, int n)
 	for (int s = 0; s < CNT_SLOTS; ++s)
 		for (int i = 0; i < CNT_N; ++i) {
 			const uint64_t v = rows[(size_t)s * CNT_N + i];
-			const bool is_max = i == CNT_MAX_EXT || (i >= 8 && i <= 15) || (i >= 21 && i <= 23);
+			const bool is_max = i == CNT_MAX_EXT || (i >= 8 && i <= 15) || (i >= 21 && i <= 23);   // the *_max entries
 			h[i] = is_max ? std::max(h[i], v) : h[i] + v;
 		}
 	for (int i = 0; i < n; ++i) counters[i] = i < CNT_N ? h[i] : 0;
