@@ -171,7 +171,7 @@ def main():
             out["roofline"]["measured_gather64_GBps"] = ceil["gather64_GBps"]
             out["roofline"]["measured_stream_copy_GBps"] = ceil["stream_copy_GBps"]
             out["roofline"]["frac_of_measured_gather"] = round(achieved / ceil["gather64_GBps"], 4)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:               # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(tp, bw, prefix, genome, lens, args, workdir)
         print(json.dumps(out), flush=True)
     if world > 1:

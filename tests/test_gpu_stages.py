@@ -99,6 +99,44 @@ def test_regions_with_forced_ahead_of_time_extension(ctx, small_index, tmp_path,
     common.assert_stage_equal(got, want, bw.STAGE_REGS, f"regions[spec_min={spec_min}]")
 
 
+_ADOPT_SCRIPT = r"""
+import sys, os
+import numpy as np
+import torch                                  # first, as in bench.py: torch brings its own HIP runtime into the process
+torch.cuda.set_device(0)
+root, prefix, fq, obin = sys.argv[1:5]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "bwa-mem-gpu_amd"))
+import common
+from common import bw
+import tools_py as tp
+meta, arrays = tp.load_index_arrays(prefix)
+tensors = {k: torch.from_numpy(v).to("cuda:0") for k, v in arrays.items()}
+torch.cuda.synchronize()
+ctx = bw.Context.from_device_arrays(meta, tensors["bwt"].data_ptr(), tensors["sa"].data_ptr(), tensors["pac"].data_ptr(), 0)
+_, seqs, _ = bw.read_fastq(fq)
+want = common.by_read(common.oracle_stages(prefix, fq, obin))
+codes, off = bw.pack_reads(seqs)
+got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_INTV, bw.STAGE_REGS]))
+common.assert_stage_equal(got, want, bw.STAGE_INTV, "intervals[adopted index]")
+common.assert_stage_equal(got, want, bw.STAGE_REGS, "regions[adopted index]")
+ctx.close()
+print("ADOPT_OK", len(got))
+"""
+
+
+def test_context_on_adopted_device_arrays(small_index, tmp_path):
+    """bwahip_init_device: the index arrays already sit in HBM as torch tensors (what every rank but 0 holds after the
+    RCCL broadcast in bench.py); the context adopts them zero-copy and must give the oracle's results.  Own process,
+    torch initialised first, exactly like a bench.py rank."""
+    import subprocess, sys
+    fq, _ = _reads(small_index, tmp_path, "adopt", 1500, 150, 10000, 2000, 500, 121, 20000)
+    script = tmp_path / "adopt.py"
+    script.write_text(_ADOPT_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), common.ROOT, small_index["prefix"], fq, str(tmp_path / "o.bin")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ADOPT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_interval_list_overflow_is_rerun_on_the_gpu(ctx, small_index, tmp_path, monkeypatch):
     """A per-read interval capacity that is too small must be detected by k_smem and the batch re-run with more room
     (no CPU path): start with room for 3 intervals per read."""
