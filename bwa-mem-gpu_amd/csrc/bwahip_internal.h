@@ -156,6 +156,7 @@ struct ExtLaunch {
 	// k_extend_spec: best seed of chain ci of read r extended ahead of time into spec_regs[seed_base[r] + ci], for reads with
 	// >= spec_min_chains chains (spec_regs == nullptr: off)
 	DevReg *spec_regs; int2 *spec_items; int *spec_n; int spec_min_chains;
+	int rank_sort_min;                           // dedup: lists at least this long try the wavefront rank sort first (shorter: one-lane introsort hides behind other wavefronts)
 };
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
 int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st);

@@ -337,6 +337,37 @@ __device__ __forceinline__ bool reg_lt(const RegSort s, int x, int y)
 	if (s.mode == 0) return p.k64 < q.k64;
 	return p.score > q.score || (p.score == q.score && (p.k64 < q.k64 || (p.k64 == q.k64 && p.qb < q.qb)));
 }
+// Sort by ranks with the whole wavefront when no two keys are equal (then every correct sort, the reference's unstable
+// introsort included, produces the same order); returns false, leaving idx untouched, as soon as a tie exists -- the
+// caller then runs the exact introsort on one lane.  Only worth it for long lists.
+__device__ __forceinline__ bool wave_rank_sort(const RegSort c, int n, int *idx, int l)
+{
+	for (int base = 0; base < n; base += 64) {
+		const int t = base + l;
+		int rank = 0;
+		bool tie = false;
+		if (t < n) {
+			const RegKey kt = c.key[t];
+			for (int u = 0; u < n; ++u) {
+				const RegKey ku = c.key[u];
+				bool lt_ut, eq;
+				if (c.mode == 0) { lt_ut = ku.k64 < kt.k64; eq = ku.k64 == kt.k64; }
+				else {
+					eq = ku.score == kt.score && ku.k64 == kt.k64 && ku.qb == kt.qb;
+					lt_ut = ku.score > kt.score || (ku.score == kt.score && (ku.k64 < kt.k64 || (ku.k64 == kt.k64 && ku.qb < kt.qb)));
+				}
+				rank += lt_ut ? 1 : 0;
+				tie |= eq && u != t;
+			}
+		}
+		if (__ballot(tie)) return false;                     // idx[0..n) has not been touched
+		if (t < n) idx[n + rank] = t;                        // second half of idx is free (2 ints per seed slot)
+	}
+	__threadfence_block(); __syncthreads();
+	for (int i = l; i < n; i += 64) idx[i] = idx[n + i];
+	return true;
+}
+
 __device__ __forceinline__ void rs_insertion(const RegSort c, int *s, int *t)
 {
 	for (int *i = s + 1; i < t; ++i)
@@ -668,7 +699,9 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 		RegKey *keys = reinterpret_cast<RegKey*>(a.tmp_regs + rb0);   // the spare list is free until the gather below
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
+		if (n < a.rank_sort_min || !wave_rank_sort(RegSort{keys, 0}, n, idx, l)) {
+			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
+		}
 		__threadfence_block(); __syncthreads();
 		t_s1 = wall_clock64();
 		// gather into sorted order through the spare list (all lanes), then copy back
@@ -790,7 +823,9 @@ __global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
 		}
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].rb; keys[i].score = av[i].score; keys[i].qb = av[i].qb; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad); }
+		if (n < a.rank_sort_min || !wave_rank_sort(RegSort{keys, 1}, n, idx, l)) {
+			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad); }
+		}
 		__threadfence_block(); __syncthreads();
 		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
 		__threadfence_block(); __syncthreads();

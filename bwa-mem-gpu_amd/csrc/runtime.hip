@@ -487,6 +487,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = c->d_perm.ensure((size_t)(n + 4) * 4))) return rc;
 		el.kept_seeds = c->d_kept_seeds.as<int>(); el.perm = c->d_perm.as<int>() + 4; el.perm_counts = c->d_perm.as<int>();
 		el.counters = counters; el.err = err;
+		el.rank_sort_min = getenv("BWAHIP_RANK_SORT_MIN") ? atoi(getenv("BWAHIP_RANK_SORT_MIN")) : 192;
 		const int spec_min = getenv("BWAHIP_SPEC_MIN_CHAINS") ? atoi(getenv("BWAHIP_SPEC_MIN_CHAINS")) : 16;   // 0 = no ahead-of-time extension
 		if (spec_min > 0) {
 			if ((rc = c->d_spec_regs.ensure(T * sizeof(DevReg))) || (rc = c->d_spec_items.ensure(T * 8 + 16))) return rc;

@@ -86,6 +86,18 @@ def test_all_stages_match_oracle(ctx, small_index, tmp_path, name, n, length, su
         common.assert_stage_equal(got, want, st, f"{what}[{name}]")
 
 
+@pytest.mark.parametrize("rank_min", [2, 1 << 30])
+def test_dedup_with_forced_rank_sort(ctx, small_index, tmp_path, monkeypatch, rank_min):
+    """mem_sort_dedup_patch: the wavefront rank sort (taken when no two keys are equal, else the exact one-lane introsort)
+    forced onto every list of >= 2 regions, and switched off: regions after dedup must not change."""
+    monkeypatch.setenv("BWAHIP_RANK_SORT_MIN", str(rank_min))
+    fq, seqs = _reads(small_index, tmp_path, "rank", 3000, 150, 20000, 3000, 500, 123, 30000)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_REGS_PRE, bw.STAGE_REGS]))
+    common.assert_stage_equal(got, want, bw.STAGE_REGS, f"regions[rank_sort_min={rank_min}]")
+
+
 @pytest.mark.parametrize("spec_min", [0, 1, 2])
 def test_regions_with_forced_ahead_of_time_extension(ctx, small_index, tmp_path, monkeypatch, spec_min):
     """k_extend_spec (best seed of each chain extended by its own wavefront before k_extend decides) forced onto every
