@@ -34,19 +34,20 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_or(int v, i
 }
 // inclusive prefix max over the 64 lanes (lane i gets max of lanes 0..i).  A lane without a DPP source keeps `old`,
 // and old = v makes that the identity of max, so every step is a single v_max_i32_dpp.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_self(int v)
-{
-	return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
-}
+// One v_max_i32_dpp per step, in place: a lane without a DPP source is not written and so keeps its own value, the
+// identity of max.  Written as asm because the builtin form compiles to v_mov + v_mov_dpp + v_max (3 x the issue slots);
+// the s_nop 1 are the two wait states a DPP read of a just-written VGPR needs (the compiler cannot see into the asm).
 __device__ __forceinline__ int wscan_incl_max(int v, int /*ident*/)
 {
-	int t;
-	t = dpp_self<0x111, 0xf>(v); v = v > t ? v : t;           // row_shr:1
-	t = dpp_self<0x112, 0xf>(v); v = v > t ? v : t;           // row_shr:2
-	t = dpp_self<0x114, 0xf>(v); v = v > t ? v : t;           // row_shr:4
-	t = dpp_self<0x118, 0xf>(v); v = v > t ? v : t;           // row_shr:8   -> scan inside each row of 16
-	t = dpp_self<0x142, 0xa>(v); v = v > t ? v : t;           // row_bcast15 into rows 1,3
-	t = dpp_self<0x143, 0xc>(v); v = v > t ? v : t;           // row_bcast31 into rows 2,3
+	asm volatile(
+		"s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+		"s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+		"s_nop 1"
+		: "+v"(v));
 	return v;
 }
 __device__ __forceinline__ int wmax(int v) { return __builtin_amdgcn_readlane(wscan_incl_max(v, (int)0x80000000), 63); }
@@ -531,7 +532,7 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 // chain.  So the best seed of every chain of such a read is extended here, one wavefront per chain, and k_extend
 // picks the result up.  (A best seed that k_extend then skips was extended in vain; its result is never looked at.)
 template <int CPL>
-__global__ __launch_bounds__(64) void k_extend_spec(ExtLaunch a)
+__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : 1)) void k_extend_spec(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
@@ -582,7 +583,7 @@ __global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *it
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64) void k_extend(ExtLaunch a)
+__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : 1)) void k_extend(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
