@@ -304,8 +304,10 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 	const unsigned long long t_0 = wall_clock64();
 	// greedy chaining (bwamem.c:280-308)
 	c.root = bt_new(c, 0);
+	DevSeed sd_next = c.seeds[0];                               // the next seed is fetched one iteration ahead of its use
 	for (int si = 0; si < S; ++si) {
-		const DevSeed sd = c.seeds[si];
+		const DevSeed sd = sd_next;
+		if (si + 1 < S) sd_next = c.seeds[si + 1];
 		if (sd.rid < 0) continue;                               // bwamem.c:294
 		bool to_add = true;
 		if (c.n_chains) {
