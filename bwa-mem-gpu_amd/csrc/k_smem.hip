@@ -16,9 +16,10 @@
 //   sort    bwamem.c:184       k_intv_sort: by info=(qbeg<<32|qend); entries with equal info are the same bi-interval
 //                              (same query substring), so any sort yields the reference's array
 // Lists prev/curr (bwt.c:293) are ONE in-place list of 16-byte packed entries per read: curr[k] (k <= j) overwrites
-// the already consumed prev[k], so the swap of bwt.c:340 is a change of (base, n).  Its first 9*G entries live
-// in LDS (the memory system is request-rate bound on this access pattern -- see scripts/gather_bw.hip -- and the
-// list was more than half of all requests); longer lists spill to a per-group HBM area.  The per-call `mem`
+// the already consumed prev[k], so the swap of bwt.c:340 is a change of (base, n).  The 8*G entries at the top of the
+// list -- the part the backward sweep works on -- live in an LDS ring (the memory system is request-rate bound on this
+// access pattern -- see scripts/gather_bw.hip -- and the list was more than half of all requests); the bottom of longer
+// lists is moved to a per-group HBM area as the forward pass overwrites the ring.  The per-call `mem`
 // vector of bwt_smem1a is not materialised: only its last start coordinate is needed (bwt.c:333).
 // Every lane of a group keeps an identical copy of the state; lane 0 of the group writes the LDS entries.
 #include "fmi_dev.h"
@@ -137,17 +138,17 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 	const DevIndex &ix = a.ix;
 	const int min_seed_len = a.opt.min_seed_len, cap = a.cap, lcap = a.lcap;
 
-	constexpr int LL = 9 * G;                                // list entries kept in LDS per read
+	constexpr int LL = 8 * G;                                // list entries kept in LDS per read (a power of two: ring index)
 	__shared__ uint4 lds_list[(256 / G) * (LL + 1)];         // +1: rows start on different banks
 	uint4 *const lrow = lds_list + (threadIdx.x / G) * (LL + 1);
-	uint4 *const spill = reinterpret_cast<uint4*>(a.scratch) + (size_t)group * lcap;   // list entries LL.. (lcap of them)
+	uint4 *const spill = reinterpret_cast<uint4*>(a.scratch) + (size_t)group * lcap;   // list entries by physical index (lcap of them)
 	DevIntv *U = a.raw;                                      // unsorted accumulated intervals of the current read (its raw row)
 
 	// ---- per-group state (identical in every lane of the group; plain scalars so it stays in registers) ----
 	int st = ST_IDLE, rd = -1, len = 0, pass = 0;
 	const uint64_t *qrow = nullptr; uint64_t qw = 0; int qwi = -1;
 	int x = 0, i = 0, j = 0, c = 0, min_intv = 1, ret = 0, p2k = 0, old_n = 0, out_n = 0;
-	int prev_n = 0, curr_n = 0, base = 0, mem_n = 0, mem_last_start = 0;
+	int prev_n = 0, curr_n = 0, base = 0, top = 0, mem_n = 0, mem_last_start = 0;
 	uint64_t curr_last_x2 = 0, p_info = 0;
 	Bi ik = { 0, 0, 0 };
 	uint32_t ik_end = 0, last_push_end = 0;
@@ -155,21 +156,29 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 	bool exhausted = false;
 	unsigned int n_ext = 0, n_blk = 0, n_out = 0;
 
-	// physical slot P of the list: LDS below LL, HBM spill above
+	// Where list entry P (physical index) lives.  The backward sweep always works on the top of the region the forward pass
+	// filled -- [base, top) with top fixed -- so LDS is a ring over the physical index that ends up holding the LL highest
+	// entries: the forward pass writes entry P to ring slot P % LL and, from P = LL on, first moves the entry it displaces
+	// (P - LL) to its HBM slot; afterwards entry P is in LDS iff P >= top - LL.  Lists of up to LL entries never touch HBM.
+#define LDS_SLOT(P) ((P) & (LL - 1))
 #define LIST_PUT(P, X0, X1, X2, END) do { \
 		const int p_ = (P); const uint4 v_ = pack_entry((X0), (X1), (X2), (uint32_t)(END)); \
-		if (p_ < LL) { if (gl == 0) lrow[p_] = v_; } else spill[p_ - LL] = v_; } while (0)
+		if (p_ >= top - LL) { if (gl == 0) lrow[LDS_SLOT(p_)] = v_; } else spill[p_] = v_; } while (0)
 	// (the LDS read is unconditional so that the two sources stay a ds_read_b128 and a global_load_dwordx4: written as
 	// an if/else the compiler merges them into four flat_load_dword through a generic pointer)
 #define LIST_GET(P, X0, X1, X2, END) do { \
 		const int p_ = (P); \
-		uint4 v_ = lrow[p_ < LL ? p_ : 0]; \
+		uint4 v_ = lrow[LDS_SLOT(p_)]; \
 		asm volatile("" : "+v"(v_.x), "+v"(v_.y), "+v"(v_.z), "+v"(v_.w)); \
-		if (p_ >= LL) v_ = spill[p_ - LL]; \
+		if (p_ < top - LL) v_ = spill[p_]; \
 		unpack_entry(v_, (X0), (X1), (X2), (END)); } while (0)
 	// backward phase: prev[jj] is read last-pushed-first (bwt.c:321-324 reverses curr) and stays that way in place
 #define PREV_AT(jj) (base + prev_n - 1 - (jj))
-#define FWD_PUSH(X0, X1, X2, END) do { LIST_PUT(curr_n, (X0), (X1), (X2), (END)); ++curr_n; curr_last_x2 = (X2); } while (0)
+#define FWD_PUSH(X0, X1, X2, END) do { \
+		const int p_ = curr_n; const uint4 v_ = pack_entry((X0), (X1), (X2), (uint32_t)(END)); \
+		if (p_ >= LL) { uint4 ev_ = lrow[LDS_SLOT(p_)]; asm volatile("" : "+v"(ev_.x), "+v"(ev_.y), "+v"(ev_.z), "+v"(ev_.w)); spill[p_ - LL] = ev_; } \
+		if (gl == 0) lrow[LDS_SLOT(p_)] = v_; \
+		++curr_n; curr_last_x2 = (X2); } while (0)
 #define BWD_PUSH(X0, X1, X2, END) do { LIST_PUT(PREV_AT(curr_n), (X0), (X1), (X2), (END)); ++curr_n; curr_last_x2 = (X2); } while (0)
 	// kv_push(a->mem, ...) of bwamem.c:151,164,174
 #define EMIT(X0, X1, X2, INFO) do { if (out_n < cap) put(U + out_n, (X0), (X1), (X2), (INFO)); ++out_n; } while (0)
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 #define FWD_FINISH() do { \
 		ret = (int)last_push_end; \
 		__builtin_amdgcn_wave_barrier(); \
-		prev_n = curr_n; base = 0; curr_n = 0; \
+		prev_n = curr_n; top = curr_n; base = 0; curr_n = 0; \
 		i = x - 1; j = 0; c = BASE_AT(i); st = ST_BWD; } while (0)
 	// bwt.c:343 break; pass 1 continues at the forward end (bwamem.c:146)
 #define BWD_FINISH() do { st = ST_NEXT; if (pass == 1) x = ret; } while (0)
@@ -317,6 +326,7 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 #undef BWD_PUSH
 #undef LIST_PUT
 #undef LIST_GET
+#undef LDS_SLOT
 #undef EMIT
 #undef FOUND_MEM
 #undef BASE_AT
