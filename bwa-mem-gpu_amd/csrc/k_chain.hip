@@ -29,6 +29,7 @@ struct ReadCtx {
 	ChainW *cw; int n_chains;
 	int *nxt;
 	BtNode *nodes; int n_nodes, root;
+	bool coop; int lane;                                        // k_chain_big: the 64 lanes run the read together (uniform control flow)
 	int *ord, *wts, *kept, *first, *keep_list, *stack;
 };
 
@@ -117,6 +118,105 @@ __device__ void bt_put(ReadCtx &c, int k)
 		if (c.nodes[x->ptr[i]].n == BT_MAXK) {
 			bt_split(c, xi, i, x->ptr[i]);
 			x = &c.nodes[xi];
+			if (pos > x->pos[i]) ++i;
+		}
+		xi = x->ptr[i];
+	}
+}
+
+
+// ---- k_chain_big: the same B-tree, driven by a whole wavefront.  Control flow is uniform (every lane executes the read);
+// inside a node the lanes split the work: lane m holds key m, so the search is one compare and a ballot, and the
+// shifts of an insert / split are one element per lane.  Nodes live in LDS; lane 0 does the single-element stores.
+__device__ __forceinline__ void wsync()
+{
+	// orders the LDS node accesses of the lanes of this wavefront; deliberately NOT a full fence: waiting for the
+	// outstanding global stores (chain records, seed links) several times per seed was the cost of this kernel
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int64_t wread64(int64_t v, int src)
+{
+	return (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src) | (uint64_t)(uint32_t)__shfl((int)((uint64_t)v >> 32), src) << 32);
+}
+__device__ __forceinline__ int wbt_find(const BtNode *x, int64_t pos, int l, int *r)
+{
+	const int n = x->n;
+	if (n == 0) return -1;
+	const int64_t pm = l < BT_MAXK ? x->pos[l] : 0;
+	int begin = __popcll(__ballot(l < n && pm < pos));          // keys ascend: the lanes below `pos` are a prefix
+	if (begin == n) { *r = 1; return n - 1; }
+	*r = cmp_pos(pos, wread64(pm, begin));
+	if (*r < 0) --begin;
+	return begin;
+}
+__device__ int wbt_lower(const ReadCtx &c, int64_t pos)
+{
+	int xi = c.root, lower = -1;
+	for (;;) {
+		const BtNode *x = &c.nodes[xi];
+		int r = 0, i = wbt_find(x, pos, c.lane, &r);
+		if (i >= 0 && r == 0) return x->key[i];
+		if (i >= 0) lower = x->key[i];
+		if (!x->is_internal) return lower;
+		xi = x->ptr[i + 1];
+	}
+}
+__device__ int wbt_new(ReadCtx &c, int is_internal)
+{
+	if (c.lane == 0) { BtNode *z = &c.nodes[c.n_nodes]; z->is_internal = is_internal; z->n = 0; }
+	return c.n_nodes++;
+}
+__device__ void wbt_split(ReadCtx &c, int xi, int i, int yi)
+{
+	const int l = c.lane;
+	const int y_internal = c.nodes[yi].is_internal;
+	const int zi = wbt_new(c, y_internal);
+	BtNode *x = &c.nodes[xi], *y = &c.nodes[yi], *z = &c.nodes[zi];
+	const int xn = x->n;
+	int mk = 0, mp = 0, sk = 0, sptr = 0; int64_t mpos = 0, spos = 0;
+	if (l < BT_T - 1) { mk = y->key[l + BT_T]; mpos = y->pos[l + BT_T]; }
+	if (y_internal && l < BT_T) mp = y->ptr[l + BT_T];
+	if (l > i && l <= xn) sptr = x->ptr[l];
+	if (l >= i && l < xn) { sk = x->key[l]; spos = x->pos[l]; }
+	const int upk = y->key[BT_T - 1]; const int64_t uppos = y->pos[BT_T - 1];
+	wsync();
+	if (l < BT_T - 1) { z->key[l] = mk; z->pos[l] = mpos; }
+	if (y_internal && l < BT_T) z->ptr[l] = mp;
+	if (l > i && l <= xn) x->ptr[l + 1] = sptr;
+	if (l >= i && l < xn) { x->key[l + 1] = sk; x->pos[l + 1] = spos; }
+	wsync();
+	if (l == 0) { z->n = BT_T - 1; y->n = BT_T - 1; x->ptr[i + 1] = zi; x->key[i] = upk; x->pos[i] = uppos; x->n = xn + 1; }
+	wsync();
+}
+__device__ void wbt_put(ReadCtx &c, int k, int64_t pos)
+{
+	const int l = c.lane;
+	if (c.nodes[c.root].n == BT_MAXK) {
+		const int s = wbt_new(c, 1);
+		if (l == 0) c.nodes[s].ptr[0] = c.root;
+		wsync();
+		wbt_split(c, s, 0, c.root);
+		c.root = s;
+	}
+	int xi = c.root;
+	for (;;) {
+		BtNode *x = &c.nodes[xi];
+		int r = 0;
+		if (!x->is_internal) {
+			const int i = wbt_find(x, pos, l, &r), n = x->n;
+			int sk = 0; int64_t spos = 0;
+			if (l > i && l < n) { sk = x->key[l]; spos = x->pos[l]; }
+			wsync();
+			if (l > i && l < n) { x->key[l + 1] = sk; x->pos[l + 1] = spos; }
+			if (l == 0) { x->key[i + 1] = k; x->pos[i + 1] = pos; x->n = n + 1; }
+			wsync();
+			return;
+		}
+		int i = wbt_find(x, pos, l, &r) + 1;
+		const int child = x->ptr[i];
+		if (c.nodes[child].n == BT_MAXK) {
+			wbt_split(c, xi, i, child);
 			if (pos > x->pos[i]) ++i;
 		}
 		xi = x->ptr[i];
@@ -281,7 +381,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 	c.keep_list = a.keep_list + sb;
 	c.nodes = BIG ? lds_nodes : reinterpret_cast<BtNode*>(a.nodes_) + (sb >> 2) + 4 * (int64_t)r;
 	c.stack = a.stack + 256 * (int64_t)r;
-	c.n_chains = 0; c.n_nodes = 0;
+	c.n_chains = 0; c.n_nodes = 0; c.coop = BIG; c.lane = (int)(threadIdx.x & 63);
 	a.chain_n[r] = 0; a.kept_seeds[r] = 0;
 	if (a.dbg_chain_n) a.dbg_chain_n[r] = 0;
 	if (S == 0) return;
@@ -303,7 +403,8 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 
 	const unsigned long long t_0 = wall_clock64();
 	// greedy chaining (bwamem.c:280-308)
-	c.root = bt_new(c, 0);
+	c.root = BIG ? wbt_new(c, 0) : bt_new(c, 0);
+	if (BIG) wsync();
 	DevSeed sd_next = c.seeds[0];                               // the next seed is fetched one iteration ahead of its use
 	for (int si = 0; si < S; ++si) {
 		const DevSeed sd = sd_next;
@@ -311,7 +412,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 		if (sd.rid < 0) continue;                               // bwamem.c:294
 		bool to_add = true;
 		if (c.n_chains) {
-			int lower = bt_lower(c, sd.rbeg);
+			int lower = BIG ? wbt_lower(c, sd.rbeg) : bt_lower(c, sd.rbeg);
 			if (lower >= 0 && try_merge(c, a.opt, a.ix.l_pac, lower, si, sd)) to_add = false;
 		}
 		if (to_add) {
@@ -319,7 +420,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 			ch->pos = sd.rbeg; ch->head = ch->tail = si; ch->n = 1; ch->rid = sd.rid;
 			ch->last_rbeg = sd.rbeg; ch->first_qbeg = ch->last_qbeg = sd.qbeg; ch->last_len = sd.len; ch->pad = 0;
 			c.nxt[si] = -1;
-			bt_put(c, c.n_chains++);
+			if (BIG) { wsync(); wbt_put(c, c.n_chains++, sd.rbeg); } else bt_put(c, c.n_chains++);
 		}
 	}
 	const unsigned long long t_1 = wall_clock64();
@@ -340,7 +441,8 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 	}
 	n_chn = k;
 	if (n_chn == 0) return;
-	isort_weight(c, n_chn, c.ord);
+	if (!BIG || c.lane == 0) isort_weight(c, n_chn, c.ord);     // exact unstable introsort: one lane
+	if (BIG) wsync();
 	const unsigned long long t_2 = wall_clock64();
 	if (n_chn > FLT_SEQ_MAX && a.heavy_list) {
 		// many chains: the O(n^2) overlap filter runs wavefront-parallel in k_chain_flt; leave it the per-position data
@@ -352,7 +454,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 			fw[i] = c.wts[ci];
 		}
 		a.chain_n[r] = -n_chn;                                  // pending marker
-		a.heavy_list[atomicAdd(a.heavy_count, 1)] = r;
+		if (!BIG || c.lane == 0) a.heavy_list[atomicAdd(a.heavy_count, 1)] = r;
 		if (a.counters) { atomicMax(&cnt_row(a.counters)[8], t_1 - t_0); atomicMax(&cnt_row(a.counters)[9], t_2 - t_1); atomicMax(&cnt_row(a.counters)[12], (unsigned long long)S); atomicMax(&cnt_row(a.counters)[13], (unsigned long long)n_chn); }
 		return;
 	}
@@ -425,7 +527,6 @@ __global__ void k_chain_classify(ChainLaunch a)
 __global__ __launch_bounds__(64) void k_chain_big(ChainLaunch a)
 {
 	__shared__ BtNode nodes[BIG_NODES];
-	if (threadIdx.x != 0) return;
 	const int n_big = *a.big_count;
 	for (int h = blockIdx.x; h < n_big; h += gridDim.x) chain_read<true>(a, a.big_list[h], nodes);
 }

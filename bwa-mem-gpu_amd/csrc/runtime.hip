@@ -453,7 +453,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		cl.counters = counters;
 		if ((rc = c->d_flt.ensure(T * 32)) || (rc = c->d_heavy.ensure((size_t)(n + 4) * 4))) return rc;
 		cl.flt = c->d_flt.as<int>(); cl.heavy_list = c->d_heavy.as<int>() + 4; cl.heavy_count = c->d_heavy.as<int>();
-		const int big_min = getenv("BWAHIP_CHAIN_BIG_MIN") ? atoi(getenv("BWAHIP_CHAIN_BIG_MIN")) : 1024;   // seeds; < 0 = off
+		const int big_min = getenv("BWAHIP_CHAIN_BIG_MIN") ? atoi(getenv("BWAHIP_CHAIN_BIG_MIN")) : 512;   // seeds; < 0 = off
 		if (big_min >= 0) {
 			if ((rc = c->d_chain_big.ensure((size_t)(n + 4) * 4))) return rc;
 			HIP_TRY(hipMemsetAsync(c->d_chain_big.p, 0, 16, c->stream));
