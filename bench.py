@@ -39,6 +39,7 @@ def main():
                     help="size of the synthetic genome (GRCh38 itself is not available offline)")
     ap.add_argument("--reads", type=int, default=int(os.environ.get("BWAHIP_BENCH_READS", "1000000")))
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--sub-ppm", type=int, default=10000, help="substitution errors per million bases (configs[4]: 50000)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BWAHIP_BENCH_CPU_READS", "200000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     # ---------------- reads: every rank its own batch (seed 102 + rank), 1 % substitutions, 50 % reverse strand
     if rank != 0:
         genome = tp.make_genome(38, lens, repeats=True)
-    reads = tp.make_reads(genome, lens, args.reads, args.read_len, sub_ppm=10000, seed=102 + rank)
+    reads = tp.make_reads(genome, lens, args.reads, args.read_len, sub_ppm=args.sub_ppm, seed=102 + rank)
     codes = bw.NT4[reads.reshape(-1)]
     off = np.arange(args.reads + 1, dtype=np.int64) * args.read_len
     log(f"rank {rank}: {args.reads} reads generated")
@@ -137,7 +138,7 @@ def main():
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.reads} synthetic {args.read_len} bp SE reads (1% substitutions) per GPU vs "
+            "config": {"workload": f"{args.reads} synthetic {args.read_len} bp SE reads ({args.sub_ppm / 10000:g}% substitutions) per GPU vs "
                                    f"{args.genome_mbp} Mbp synthetic genome with repeat families (GRCh38 not available offline); "
                                    "BASELINE configs[1] shape",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
@@ -199,7 +200,7 @@ def cpu_baseline(tp, bw, prefix, genome, lens, args, workdir):
     n = min(args.cpu_sample, args.reads)
     cores = os.cpu_count() or 1
     fq = os.path.join(workdir, "cpu_sample.fq")
-    reads = tp.make_reads(genome, lens, n, args.read_len, sub_ppm=10000, seed=102)
+    reads = tp.make_reads(genome, lens, n, args.read_len, sub_ppm=args.sub_ppm, seed=102)
     tp.write_fastq(fq, reads)
     ref = os.path.join(ROOT, "oracle", "_ref", "bwaref")
     port = os.path.join(ROOT, "oracle", "bwa_oracle")

@@ -467,6 +467,19 @@ __device__ __forceinline__ bool chain_window(const DevIndex &ix, const DevOpt &o
 	return true;
 }
 
+// ksw_extend2 with the fewest columns per lane that hold the flank (qlen + 1 columns): the per-row cost grows with the
+// number of columns a lane owns, and most flanks are far shorter than the read.
+template <int CPL>
+__device__ __forceinline__ int wave_extend_fit(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
+                                               int w, int end_bonus, int zdrop, int h0, int &qle, int &tle, int &gtle, int &gscore, int &max_off, Work &wk)
+{
+	if (qlen < 64) return wave_extend<1>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	if (CPL > 2 && qlen < 128) return wave_extend<2>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	if (CPL > 3 && qlen < 192) return wave_extend<3>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	if (CPL > 4 && qlen < 256) return wave_extend<4>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	return wave_extend<CPL>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+}
+
 // Extension of one seed into an alignment region (bwamem.c:716-793): left and right ksw_extend2 with band doubling
 // (MAX_BAND_TRY = 2), clip-vs-to-end choice, seed coverage.  Needs s_q / s_t of the chain loaded.
 template <int CPL>
@@ -485,13 +498,8 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 		for (int i = 0; i < 2; ++i) {                   // MAX_BAND_TRY
 			const int prev = reg.score;
 			aw0 = opt.w << i;
-			// a flank of at most 63 bases fits one column per lane: less than half the instructions per row
-			reg.score = s.qbeg < 64 ? wave_extend<1>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, wk)
-			          : (CPL > 2 && s.qbeg < 128) ? wave_extend<2>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                         s.len * opt.a, qle, tle, gtle, gscore, max_off, wk)
-			                        : wave_extend<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                           s.len * opt.a, qle, tle, gtle, gscore, max_off, wk);
+			reg.score = wave_extend_fit<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
+			                                 s.len * opt.a, qle, tle, gtle, gscore, max_off, wk);
 			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
@@ -503,12 +511,8 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 		for (int i = 0; i < 2; ++i) {
 			const int prev = reg.score;
 			aw1 = opt.w << i;
-			reg.score = l_query - qe < 64 ? wave_extend<1>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                               qle, tle, gtle, gscore, max_off, wk)
-			          : (CPL > 2 && l_query - qe < 128) ? wave_extend<2>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                               qle, tle, gtle, gscore, max_off, wk)
-			                              : wave_extend<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                                 qle, tle, gtle, gscore, max_off, wk);
+			reg.score = wave_extend_fit<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
+			                                 qle, tle, gtle, gscore, max_off, wk);
 			if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
@@ -909,6 +913,7 @@ int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st)
 	hipLaunchKernelGGL(k_spec_items, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.chain_n, a.spec_min_chains, a.spec_items, a.spec_n);
 	const int grid = 16384;
 	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend_spec<3>, dim3(grid), dim3(64), 0, st, a);
+	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_extend_spec<4>, dim3(grid), dim3(64), 0, st, a);
 	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend_spec<5>, dim3(grid), dim3(64), 0, st, a);
 	else hipLaunchKernelGGL(k_extend_spec<11>, dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
@@ -923,6 +928,7 @@ int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 	}
 	// columns 0..max_len must fit in 64 lanes x CPL registers
 	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend<3>, dim3(a.n_reads), dim3(64), 0, st, a);
+	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_extend<4>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend<5>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else hipLaunchKernelGGL(k_extend<11>, dim3(a.n_reads), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
