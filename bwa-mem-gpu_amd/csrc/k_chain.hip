@@ -433,16 +433,42 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 	// ---- mem_chain_flt (bwamem.c:334-392)
 	if (n_chn == 0) return;
 	int k = 0;
-	for (int i = 0; i < n_chn; ++i) {
-		int ci = c.ord[i];
-		c.first[ci] = -1; c.kept[ci] = 0;
-		c.wts[ci] = chain_weight(c, ci);
-		if (c.wts[ci] >= a.opt.min_chain_weight) c.ord[k++] = ci;
+	if (BIG) {                                                  // weights: one chain per lane (each walks its own seed list)
+		for (int i = c.lane; i < n_chn; i += 64) {
+			const int ci = c.ord[i];
+			c.first[ci] = -1; c.kept[ci] = 0;
+			c.wts[ci] = chain_weight(c, ci);
+		}
+		__threadfence_block(); __builtin_amdgcn_wave_barrier();
+		for (int i = 0; i < n_chn; ++i) { const int ci = c.ord[i]; if (c.wts[ci] >= a.opt.min_chain_weight) c.ord[k++] = ci; }
+	} else {
+		for (int i = 0; i < n_chn; ++i) {
+			int ci = c.ord[i];
+			c.first[ci] = -1; c.kept[ci] = 0;
+			c.wts[ci] = chain_weight(c, ci);
+			if (c.wts[ci] >= a.opt.min_chain_weight) c.ord[k++] = ci;
+		}
 	}
 	n_chn = k;
 	if (n_chn == 0) return;
-	if (!BIG || c.lane == 0) isort_weight(c, n_chn, c.ord);     // exact unstable introsort: one lane
-	if (BIG) wsync();
+	if (BIG) {
+		// the exact unstable introsort runs on one lane; the B-tree is no longer needed, so its LDS holds the index array
+		// and the weights while it runs (what the sort waits for is the latency of its fetches)
+		int *l_ord = reinterpret_cast<int*>(lds_nodes), *l_wts = l_ord + n_chn, *l_stk = l_wts + c.n_chains;
+		const bool fits = (size_t)(n_chn + c.n_chains + 256) * 4 <= (size_t)BIG_NODES * sizeof(BtNode);
+		if (fits) {
+			for (int i = c.lane; i < n_chn; i += 64) l_ord[i] = c.ord[i];
+			for (int i = c.lane; i < c.n_chains; i += 64) l_wts[i] = c.wts[i];
+			wsync();
+			if (c.lane == 0) { ReadCtx cl = c; cl.wts = l_wts; cl.stack = l_stk; isort_weight(cl, n_chn, l_ord); }
+			wsync();
+			for (int i = c.lane; i < n_chn; i += 64) c.ord[i] = l_ord[i];
+			__threadfence_block(); __builtin_amdgcn_wave_barrier();
+		} else {
+			if (c.lane == 0) isort_weight(c, n_chn, c.ord);
+			__threadfence_block(); __builtin_amdgcn_wave_barrier();
+		}
+	} else isort_weight(c, n_chn, c.ord);                       // exact unstable introsort
 	const unsigned long long t_2 = wall_clock64();
 	if (n_chn > FLT_SEQ_MAX && a.heavy_list) {
 		// many chains: the O(n^2) overlap filter runs wavefront-parallel in k_chain_flt; leave it the per-position data
