@@ -547,14 +547,25 @@ __global__ void k_chain_classify(ChainLaunch a)
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= a.n_reads) return;
 	const int S = (int)(a.seed_base[r + 1] - a.seed_base[r]);
-	if (S > a.big_min && S <= a.big_max) a.big_list[atomicAdd(a.big_count, 1)] = r;
+	if (S > a.big_min && S <= a.big_max) {
+		// the longest first (from the front of the list), the rest from the back: k_chain_big takes them in that order
+		if (S > 2 * a.big_min) a.big_list[atomicAdd(&a.big_count[1], 1)] = r;
+		else a.big_list[a.n_reads - 1 - atomicAdd(&a.big_count[0], 1)] = r;
+	}
 }
 
 __global__ __launch_bounds__(64) void k_chain_big(ChainLaunch a)
 {
 	__shared__ BtNode nodes[BIG_NODES];
-	const int n_big = *a.big_count;
-	for (int h = blockIdx.x; h < n_big; h += gridDim.x) chain_read<true>(a, a.big_list[h], nodes);
+	const int n_lo = a.big_count[0], n_hi = a.big_count[1];
+	for (;;) {                                                   // work queue: a workgroup that finishes takes the next read
+		int h = 0;
+		if ((threadIdx.x & 63) == 0) h = atomicAdd(&a.big_count[2], 1);
+		h = __shfl(h, 0);
+		if (h >= n_lo + n_hi) break;
+		chain_read<true>(a, a.big_list[h < n_hi ? h : a.n_reads - 1 - (h - n_hi)], nodes);
+		wsync();
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------
