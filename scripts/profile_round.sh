@@ -1,11 +1,9 @@
 #!/bin/bash
-# Round profile: default bench line, rocprofv3 kernel stats of the same command, PMC passes (own runs).
-#   gpurun --timeout 1100 -- scripts/profile_round.sh <tag>
+# Round profile: rocprofv3 kernel stats of the default bench command, PMC passes (own runs), then the default bench line
+# itself (last, so that it can quote the traffic of these very PMC passes).
+#   gpurun --timeout 1100 -- scripts/profile_round.sh <tag> <round-dir>
 set -e
-TAG=${1:-prof}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
-python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
-echo "bench done"; tail -c 600 $OUT/bench_default.json
+TAG=${1:-prof}; ROUND=${2:-profiles/r01}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log || echo "trace failed"
 echo "trace done"
@@ -15,3 +13,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCP_T
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc$i.json 2> $OUT/pmc$i.log || echo "pmc pass $i failed"
   echo "pmc $i done"
 done
+cd $GRAFT_REPO_ROOT
+touch $OUT/bench_default.json
+python3 scripts/collect_profiles.py $TAG $ROUND --traffic-only > /dev/null
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
+echo "bench done"; tail -c 700 $OUT/bench_default.json

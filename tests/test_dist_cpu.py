@@ -34,9 +34,13 @@ def test_index_broadcast_and_sharding_world_size_2(small_index, tmp_path):
     import json
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as sk:                      # a port that is free right now (a fixed one can linger in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(script), common.ROOT, small_index["prefix"]]
+           "--master-port", port, str(script), common.ROOT, small_index["prefix"]]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
     res = sorted((json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l), key=lambda x: x["rank"])
