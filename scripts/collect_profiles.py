@@ -10,7 +10,8 @@ os.makedirs(dst, exist_ok=True)
 if not traffic_only:
     shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
     shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, "bench_under_rocprof_trace.json"))
-    ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    # rocprofv3 writes one set of files per process; bench.py also runs the gather microbenchmark as a child: take bench.py's
+    ks = [f for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True) if "k_smem" in open(f).read()]
     if ks:
         shutil.copy(ks[0], os.path.join(dst, "kernel_stats_bench_default.csv"))
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
