@@ -74,6 +74,18 @@ struct DevReg {
 	int32_t pad;
 };
 
+#include <thread>
+#include <vector>
+// host helper: f(begin, end) on nt threads over contiguous chunks of [0, n)
+template <class F> static inline void par_for_chunks(int64_t n, int nt, F f)
+{
+	if (nt <= 1 || n < 4096) { f((int64_t)0, n); return; }
+	std::vector<std::thread> th;
+	const int64_t per = (n + nt - 1) / nt;
+	for (int t = 0; t < nt; ++t) { const int64_t b = t * per, e = b + per < n ? b + per : n; if (b < e) th.emplace_back(f, b, e); }
+	for (auto &x : th) x.join();
+}
+
 struct HostIndex {           // host copy of a loaded index (index_io.cpp)
 	bwahip_bwt_t bwt;
 	bwahip_bns_t bns;

@@ -1041,7 +1041,9 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	int rc = bwahip_align_batch(ctx, opt, n, seqs, regs_c.data());
 	if (rc) return rc;
 	std::vector<hf::RegV> regs(n);
-	for (int i = 0; i < n; ++i) { regs[i].a.assign(regs_c[i].a, regs_c[i].a + regs_c[i].n); free(regs_c[i].a); }
+	par_for_chunks(n, opt->n_threads, [&](int64_t b, int64_t e) {
+		for (int64_t i = b; i < e; ++i) { regs[i].a.assign(regs_c[i].a, regs_c[i].a + regs_c[i].n); free(regs_c[i].a); }
+	});
 	hf::Ref ref = { bns, pac, bns->l_pac };
 	// phase 2 (serial): insert-size statistics (bwamem.c:1236-1239)
 	bwahip_pestat_t pes[4];
@@ -1055,8 +1057,9 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	std::atomic<int> next(0), bad(0);
 	auto work = [&]() {
 		for (;;) {
-			int i = next.fetch_add(1);
-			if (i >= n_items) break;
+			const int i0 = next.fetch_add(64);                   // 64 items per grab: one shared counter, hundreds of threads
+			if (i0 >= n_items) break;
+			for (int i = i0; i < n_items && i < i0 + 64; ++i)
 			if (!pe) {
 				hf::Read s = { seqs[i].name, seqs[i].comment, seqs[i].qual, seqs[i].seq, seqs[i].l_seq };
 				hf::mark_primary_se(*opt, (int)regs[i].a.size(), regs[i].a.data(), n_processed + i);

@@ -4,6 +4,7 @@
 #include "bwahip_internal.h"
 #include <math.h>
 #include <algorithm>
+#include <atomic>
 
 // ------------------------------------------------------------------ small device helpers
 struct DevBuf {
@@ -548,7 +549,7 @@ int bwahip_batch_counters(bwahip_ctx *c, uint64_t *counters, int n)
 	return 0;
 }
 
-int bwahip_batch_download(bwahip_ctx *c, bwahip_alnreg_v *out)
+static int batch_download_mt(bwahip_ctx *c, bwahip_alnreg_v *out, int nt)
 {
 	if (!c || !out) return BWAHIP_EINVAL;
 	HIP_TRY(hipSetDevice(c->device));
@@ -560,21 +561,25 @@ int bwahip_batch_download(bwahip_ctx *c, bwahip_alnreg_v *out)
 	HIP_TRY(hipMemcpy(h_regn.data(), c->d_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(h_rbase.data(), c->d_reg_base.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
 	if (c->total_regs) HIP_TRY(hipMemcpy(h_regs.data(), c->d_regs.p, (size_t)c->total_regs * sizeof(DevReg), hipMemcpyDeviceToHost));
-	for (int i = 0; i < n; ++i) {
-		const int m = h_regn[i];
-		out[i].n = out[i].m = m;
-		out[i].a = m ? (bwahip_alnreg_t*)calloc(m, sizeof(bwahip_alnreg_t)) : nullptr;   // kv_init'ed vector when empty (bwamem.c:1075)
-		if (m && !out[i].a) return BWAHIP_ENOMEM;
-		for (int k = 0; k < m; ++k) {
-			const DevReg &p = h_regs[h_rbase[i] + k];
-			bwahip_alnreg_t &q = out[i].a[k];                  // memset(0) + the fields mem_chain2aln / dedup set
-			q.rb = p.rb; q.re = p.re; q.frac_rep = p.frac_rep; q.qb = p.qb; q.qe = p.qe; q.rid = p.rid; q.score = p.score; q.truesc = p.truesc;
-			q.sub = p.sub; q.csub = p.csub; q.sub_n = p.sub_n; q.w = p.w; q.seedcov = p.seedcov; q.seedlen0 = p.seedlen0;
-			q.n_comp = p.n_comp; q.is_alt = p.is_alt;
+	std::atomic<int> oom(0);
+	par_for_chunks(n, nt, [&](int64_t b, int64_t e) {
+		for (int64_t i = b; i < e; ++i) {
+			const int m = h_regn[i];
+			out[i].n = out[i].m = m;
+			out[i].a = m ? (bwahip_alnreg_t*)calloc(m, sizeof(bwahip_alnreg_t)) : nullptr;   // kv_init'ed vector when empty (bwamem.c:1075)
+			if (m && !out[i].a) { oom = 1; out[i].n = out[i].m = 0; continue; }
+			for (int k = 0; k < m; ++k) {
+				const DevReg &p = h_regs[h_rbase[i] + k];
+				bwahip_alnreg_t &q = out[i].a[k];              // memset(0) + the fields mem_chain2aln / dedup set
+				q.rb = p.rb; q.re = p.re; q.frac_rep = p.frac_rep; q.qb = p.qb; q.qe = p.qe; q.rid = p.rid; q.score = p.score; q.truesc = p.truesc;
+				q.sub = p.sub; q.csub = p.csub; q.sub_n = p.sub_n; q.w = p.w; q.seedcov = p.seedcov; q.seedlen0 = p.seedlen0;
+				q.n_comp = p.n_comp; q.is_alt = p.is_alt;
+			}
 		}
-	}
-	return 0;
+	});
+	return oom ? BWAHIP_ENOMEM : 0;
 }
+int bwahip_batch_download(bwahip_ctx *c, bwahip_alnreg_v *out) { return batch_download_mt(c, out, 1); }
 
 // ------------------------------------------------------------------ stage dump (i64 records)
 static void rec(std::vector<int64_t> &o, int64_t tag, const std::vector<int64_t> &v)
@@ -694,14 +699,16 @@ int bwahip_align_batch(bwahip_ctx *c, const bwahip_opt_t *opt, int n, bwahip_seq
 	std::vector<int64_t> off(n + 1, 0);
 	for (int i = 0; i < n; ++i) { if (seqs[i].l_seq < 0) return BWAHIP_EINVAL; off[i + 1] = off[i] + seqs[i].l_seq; }
 	std::vector<uint8_t> codes((size_t)off[n] + 1);
-	for (int i = 0; i < n; ++i) {                         // in-place conversion exactly as bwamem.c:1067-1068
-		char *s = seqs[i].seq;
-		for (int k = 0; k < seqs[i].l_seq; ++k) { s[k] = s[k] < 4 ? s[k] : (char)k_nt4[(uint8_t)s[k]]; codes[off[i] + k] = (uint8_t)s[k]; }
-	}
+	par_for_chunks(n, opt->n_threads, [&](int64_t b, int64_t e) {   // in-place conversion exactly as bwamem.c:1067-1068
+		for (int64_t i = b; i < e; ++i) {
+			char *s = seqs[i].seq;
+			for (int k = 0; k < seqs[i].l_seq; ++k) { s[k] = s[k] < 4 ? s[k] : (char)k_nt4[(uint8_t)s[k]]; codes[off[i] + k] = (uint8_t)s[k]; }
+		}
+	});
 	int rc = bwahip_batch_upload(c, n, codes.data(), off.data());
 	if (rc) return rc;
 	if ((rc = run_pipeline(c, opt, false, false))) return rc;
-	return bwahip_batch_download(c, regs_out);
+	return batch_download_mt(c, regs_out, opt->n_threads);
 }
 int bwahip_kat_ksw_extend(bwahip_ctx *c, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff, int *out6)
 {
