@@ -138,9 +138,7 @@ __device__ int wave_extend(const Sw &sw, const uint8_t *q, int qs, int qlen, con
 		int h1 = 0;
 		if (beg == 0) { h1 = h0 - (sw.o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
 		wk.cells += end > beg ? (unsigned)(end - beg) : 0u;          // wavefront-uniform; lane 0 reports it
-#ifndef NO_ROWS
 		if (CPL == 1) ++wk.rows1; else ++wk.rowsN;
-#endif
 		int M[CPL], u[CPL], P = NEG;
 #pragma unroll
 		for (int c = 0; c < CPL; ++c) {
@@ -243,9 +241,7 @@ __device__ int wave_global_score(const Sw &sw, const uint8_t *q, int qs, int qle
 		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1 = beg == 0 ? -(sw.o_del + e_del * (i + 1)) : NEG;
 		wk.cells += end > beg ? (unsigned)(end - beg) : 0u;          // wavefront-uniform; lane 0 reports it
-#ifndef NO_ROWS
 		if (CPL == 1) ++wk.rows1; else ++wk.rowsN;
-#endif
 		int M[CPL], u[CPL], P = LOW;
 #pragma unroll
 		for (int c = 0; c < CPL; ++c) {
