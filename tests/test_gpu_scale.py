@@ -43,3 +43,24 @@ def test_bench_workload_matches_oracle(bench_genome, tmp_path):
     assert cnt["heavy_intv"] > 0, "no read was handed to k_smem_heavy"
     assert cnt["max_seeds"] > 512, "no read reached k_chain_big's threshold"
     assert cnt["max_chains"] >= 16, "no read reached k_extend_spec's threshold"
+
+
+def test_bench_workload_sam_identical_to_reference(bench_genome, tmp_path):
+    """End to end on the same workload: bwahip_process_seqs vs the reference's own mem_process_seqs (oracle/_ref/bwaref
+    when present, else the C restatement), SE and PE, byte-identical SAM."""
+    import subprocess
+    import tools_py as tp
+    exe = common.BWAREF if common.have_ref() else common.ORACLE
+    n = int(os.environ.get("BWAHIP_SCALE_TEST_SAM_READS", "20000"))
+    opt = bw.default_opt()
+    opt.n_threads = 8
+    # SE
+    reads = tp.make_reads(bench_genome["genome"], bench_genome["lens"], n, 150, sub_ppm=10000, seed=131)
+    fq = str(tmp_path / "se.fq")
+    tp.write_fastq(fq, reads)
+    names, seqs, quals = bw.read_fastq(fq)
+    want = subprocess.run([exe, "mem", "-t", "8", bench_genome["prefix"], fq], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    with bw.Context(bench_genome["prefix"]) as ctx:
+        got = b"".join(ctx.process_seqs(names, seqs, quals, opt))
+        body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
+        assert body(got) == body(want), "SE SAM differs from the CPU path on the bench workload"
