@@ -54,7 +54,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        # rehearsal on a one-GPU box: BWAHIP_BENCH_BACKEND=gloo BWAHIP_BENCH_ONE_DEVICE=1 runs every rank on cuda:0
+        backend = os.environ.get("BWAHIP_BENCH_BACKEND", "nccl")
+        if os.environ.get("BWAHIP_BENCH_ONE_DEVICE"):
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
 
     import __graft_entry__ as entry
