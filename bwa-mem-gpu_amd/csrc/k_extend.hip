@@ -532,7 +532,7 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 // chain.  So the best seed of every chain of such a read is extended here, one wavefront per chain, and k_extend
 // picks the result up.  (A best seed that k_extend then skips was extended in vain; its result is never looked at.)
 template <int CPL>
-__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : 1)) void k_extend_spec(ExtLaunch a)
+__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_extend_spec(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
@@ -583,7 +583,7 @@ __global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *it
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : 1)) void k_extend(ExtLaunch a)
+__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_extend(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
