@@ -211,7 +211,11 @@ int bwahip_n_kernels(void);
 const char *bwahip_kernel_name(int i);
 /* Algorithmic work counters of the last bwahip_batch_run, counted on the device by the kernels
  * themselves: [0] bwt_extend calls, [1] Occ blocks touched by them,
- * [2] bwt_sa calls, [3] LF steps, [4] intervals written, [5] seeds, [6] DP cells. */
+ * [2] bwt_sa calls, [3] LF steps, [4] intervals written, [5] seeds, [6] DP cells, [7] most bwt_extend
+ * calls of one read; [8..15] per-phase maxima over reads (10 ns ticks) and the largest seed / chain
+ * counts of one read; [16,17] Occ blocks / intervals of k_smem_heavy, [24,25] of k_smem3 (both are
+ * included in [1] and [4]; bench.py subtracts them to attribute bytes to k_smem); [19,20] DP rows
+ * with one / several columns per lane; [21..23] dedup phase maxima.  n <= 32. */
 int bwahip_batch_counters(bwahip_ctx *ctx, uint64_t *counters, int n);
 
 /* Known-answer helpers used by the parity tests: device Occ/extend/SA on arrays of inputs. */
