@@ -265,3 +265,46 @@ def test_ksw_extend_known_answers_from_reference(ctx):
     assert len(want) >= 100
     bad = [i for i in range(len(want)) if list(got[i]) != want[i]]
     assert not bad, f"{len(bad)} of {len(want)} differ; first {bad[0]}: params={params[bad[0]]} got={list(got[bad[0]])} want={want[bad[0]]}"
+
+
+def _genome_slice(small_index, start, length):
+    seq = []
+    with open(small_index["fa"], "rb") as f:
+        f.readline()
+        for line in f:
+            if line.startswith(b">"):
+                break
+            seq.append(line.strip())
+    g = b"".join(seq)
+    return g[start:start + length]
+
+
+def test_edge_cases_ragged_batch(ctx, small_index, tmp_path):
+    """Empty batch; one batch mixing an empty read, reads shorter than a seed, an all-N read, a read with N runs, a read
+    of the maximum length (700) and ordinary ones: stages and SAM must equal the CPU path; 701 bases is a loud error."""
+    import subprocess
+    assert ctx.run_stages(np.zeros(0, np.uint8), np.zeros(1, np.int64), [bw.STAGE_INTV, bw.STAGE_REGS]) == []      # n = 0
+    g = _genome_slice(small_index, 1000, 4000)
+    reads = [b"", b"A", g[10:28], g[100:119], b"N" * 150, g[200:260] + b"NNNNN" + g[265:350], g[500:1200], g[1300:1450],
+             g[2000:2150].translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1], b"ACGT" * 40]
+    assert len(reads[6]) == 700
+    fq = str(tmp_path / "edge.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@e%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    names, seqs, quals = bw.read_fastq(fq)
+    want = common.by_read(common.oracle_stages(small_index["prefix"], fq, str(tmp_path / "o.bin")))
+    codes, off = bw.pack_reads(seqs)
+    got = common.by_read(ctx.run_stages(codes, off, [bw.STAGE_INTV, bw.STAGE_CHAIN_FLT, bw.STAGE_REGS]))
+    for st, what in [(bw.STAGE_INTV, "intervals"), (bw.STAGE_CHAIN_FLT, "filtered chains"), (bw.STAGE_REGS, "regions")]:
+        common.assert_stage_equal(got, want, st, f"{what}[edge cases]")
+    want_sam = subprocess.run([common.ORACLE, "mem", "-t", "2", small_index["prefix"], fq], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    opt = bw.default_opt()
+    opt.n_threads = 2
+    got_sam = b"".join(ctx.process_seqs(names, seqs, quals, opt))
+    body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
+    assert body(got_sam) == body(want_sam)
+    too_long = [g[0:701]]
+    codes, off = bw.pack_reads(too_long)
+    with pytest.raises(bw.BwahipError, match="ECAPACITY"):
+        ctx.run_stages(codes, off, [bw.STAGE_REGS])
