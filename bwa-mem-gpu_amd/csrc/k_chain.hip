@@ -367,10 +367,11 @@ __device__ void write_chains(const ReadCtx &c, const DevIndex &ix, int n, const 
 // BIG = false: one read per lane.  Reads with big_min < seeds <= big_max are only listed; k_chain<true> then takes one
 // of them per workgroup (one working lane) with the B-tree nodes in LDS: the build is a chain of dependent node
 // visits, ~10 per seed, and a 2 000-seed read otherwise sets the duration of the whole launch through L2 latency.
-constexpr int BIG_NODES = 800;                               // 800 x 192 B = 150 KB of LDS; nodes <= seeds / 5 + a few
+constexpr int BIG_NODES = 800;                               // 800 x 192 B = 150 KB of LDS; nodes <= 0.24 x seeds + a few
+constexpr int MID_NODES = 400, MID_SEEDS = 1536;             // two workgroups per CU for the (far more common) reads up to 1536 seeds
 
 template <bool BIG>
-__device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *lds_nodes)
+__device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *lds_nodes, int lds_node_cap = BIG_NODES)
 {
 	const int64_t sb = a.seed_base[r];
 	const int S = (int)(a.seed_base[r + 1] - sb), len = (int)(a.off[r + 1] - a.off[r]);
@@ -455,7 +456,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 		// the exact unstable introsort runs on one lane; the B-tree is no longer needed, so its LDS holds the index array
 		// and the weights while it runs (what the sort waits for is the latency of its fetches)
 		int *l_ord = reinterpret_cast<int*>(lds_nodes), *l_wts = l_ord + n_chn, *l_stk = l_wts + c.n_chains;
-		const bool fits = (size_t)(n_chn + c.n_chains + 256) * 4 <= (size_t)BIG_NODES * sizeof(BtNode);
+		const bool fits = (size_t)(n_chn + c.n_chains + 256) * 4 <= (size_t)lds_node_cap * sizeof(BtNode);
 		if (fits) {
 			for (int i = c.lane; i < n_chn; i += 64) l_ord[i] = c.ord[i];
 			for (int i = c.lane; i < c.n_chains; i += 64) l_wts[i] = c.wts[i];
@@ -548,22 +549,24 @@ __global__ void k_chain_classify(ChainLaunch a)
 	if (r >= a.n_reads) return;
 	const int S = (int)(a.seed_base[r + 1] - a.seed_base[r]);
 	if (S > a.big_min && S <= a.big_max) {
-		// the longest first (from the front of the list), the rest from the back: k_chain_big takes them in that order
-		if (S > 2 * a.big_min) a.big_list[atomicAdd(&a.big_count[1], 1)] = r;
+		// the few longest ones go to the front of the list (k_chain_big<BIG_NODES>, one workgroup per CU), the rest to the
+		// back (k_chain_big<MID_NODES>, two per CU); both kernels run beside k_chain on their own streams
+		if (S > MID_SEEDS) a.big_list[atomicAdd(&a.big_count[1], 1)] = r;
 		else a.big_list[a.n_reads - 1 - atomicAdd(&a.big_count[0], 1)] = r;
 	}
 }
 
+template <int NODES, bool HI>
 __global__ __launch_bounds__(64) void k_chain_big(ChainLaunch a)
 {
-	__shared__ BtNode nodes[BIG_NODES];
-	const int n_lo = a.big_count[0], n_hi = a.big_count[1];
+	__shared__ BtNode nodes[NODES];
+	const int n_mine = a.big_count[HI ? 1 : 0];
 	for (;;) {                                                   // work queue: a workgroup that finishes takes the next read
 		int h = 0;
-		if ((threadIdx.x & 63) == 0) h = atomicAdd(&a.big_count[2], 1);
+		if ((threadIdx.x & 63) == 0) h = atomicAdd(&a.big_count[HI ? 2 : 3], 1);
 		h = __shfl(h, 0);
-		if (h >= n_lo + n_hi) break;
-		chain_read<true>(a, a.big_list[h < n_hi ? h : a.n_reads - 1 - (h - n_hi)], nodes);
+		if (h >= n_mine) break;
+		chain_read<true>(a, a.big_list[HI ? h : a.n_reads - 1 - h], nodes, NODES);
 		wsync();
 	}
 }
@@ -679,16 +682,17 @@ int launch_chain_flt(const ChainLaunch &a, hipStream_t st)
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
-int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
+int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipStream_t st3, hipEvent_t fork, hipEvent_t join, hipEvent_t join3)
 {
 	if (a.n_reads <= 0) return 0;
-	if (a.big_list) {                                        // many-seed reads: own kernel, concurrent with the rest
+	if (a.big_list) {                                        // many-seed reads: own kernels, concurrent with the rest
 		hipLaunchKernelGGL(k_chain_classify, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
-		if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess) return BWAHIP_ENODEV;
-		hipLaunchKernelGGL(k_chain_big, dim3(1024), dim3(64), 0, st2, a);
-		if (hipEventRecord(join, st2) != hipSuccess) return BWAHIP_ENODEV;
+		if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess || hipStreamWaitEvent(st3, fork, 0) != hipSuccess) return BWAHIP_ENODEV;
+		hipLaunchKernelGGL((k_chain_big<BIG_NODES, true>), dim3(256), dim3(64), 0, st2, a);
+		hipLaunchKernelGGL((k_chain_big<MID_NODES, false>), dim3(1024), dim3(64), 0, st3, a);
+		if (hipEventRecord(join, st2) != hipSuccess || hipEventRecord(join3, st3) != hipSuccess) return BWAHIP_ENODEV;
 	}
 	hipLaunchKernelGGL(k_chain, dim3((a.n_reads + 63) / 64), dim3(64), 0, st, a);
-	if (a.big_list && hipStreamWaitEvent(st, join, 0) != hipSuccess) return BWAHIP_ENODEV;
+	if (a.big_list && (hipStreamWaitEvent(st, join, 0) != hipSuccess || hipStreamWaitEvent(st, join3, 0) != hipSuccess)) return BWAHIP_ENODEV;
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

@@ -101,8 +101,8 @@ static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain"
 struct bwahip_ctx {
 	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
-	hipStream_t stream = nullptr, stream2 = nullptr;     // stream2: kernels that run beside the main one (k_chain_big)
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
 	HostIndex host;                      // host copy (owned when loaded from files)
 	DevIndex ix;
 	DevBuf d_bwt, d_sa, d_pac, d_anns;
@@ -180,6 +180,8 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
 	int rc;
@@ -276,6 +278,8 @@ void bwahip_destroy(bwahip_ctx *c)
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	if (c->stream3) (void)hipStreamDestroy(c->stream3);
+	if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	bwahip_free_host_index(&c->host);
@@ -463,7 +467,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		HIP_TRY(hipMemsetAsync(c->d_heavy.p, 0, 16, c->stream));
 		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }
 		if (timed) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-		if ((rc = launch_chain(cl, c->stream, c->stream2, c->ev_fork, c->ev_join))) return rc;
+		if ((rc = launch_chain(cl, c->stream, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_join3))) return rc;
 		if ((rc = launch_chain_flt(cl, c->stream))) return rc;
 		STAGE_LOG("k_chain");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
