@@ -1,11 +1,13 @@
 // K3 -- chaining and chain filtering (mem_chain body bwamem.c:272-317, mem_chain_flt bwamem.c:334-392).
 //
-// Both steps are short, strictly sequential per read and order-sensitive (greedy merge into the
-// chain with the greatest pos <= rbeg, found through a B-tree whose shape decides where duplicate
-// positions land, kbtree.h; then an UNSTABLE introsort by weight, ksort.h:176-227).  They are not the
-// bottleneck, so they run one read per lane, restating the sequential algorithms literally; all
-// working storage is per-read global memory sized from the seed count (no in-kernel allocation,
-// no local arrays: nothing goes to scratch).
+// Both steps are strictly sequential per read and order-sensitive (greedy merge into the chain with the
+// greatest pos <= rbeg, found through a B-tree whose shape decides where duplicate positions land,
+// kbtree.h; then an UNSTABLE introsort by weight, ksort.h:176-227), so the sequential algorithms are
+// restated literally.  k_chain runs one read per lane (ordinary reads: a handful of seeds); reads with
+// hundreds to thousands of seeds go to k_chain_big, where a whole wavefront drives the same B-tree in LDS
+// (they would otherwise set the duration of the launch), and the O(n^2) overlap filter of many-chain reads
+// runs in k_chain_flt.  Working storage is per-read global memory sized from the seed count (no in-kernel
+// allocation, no local arrays: nothing goes to scratch).
 //   in : seeds of the read in look-up order (K2), sorted intervals (K1) for l_rep
 //   out: filtered chains in final order with their seeds contiguous; optional pre-filter dump
 #include "bwahip_internal.h"

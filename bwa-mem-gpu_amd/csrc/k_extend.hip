@@ -6,11 +6,16 @@
 // DP on a wavefront.  Both DPs feed E and F from M (= H(i-1,j-1)+s), not from H (ksw.c:439-447,
 // 556-564), so a row has no serial dependency except F, and F is a max-plus prefix scan:
 //     F(i,j) = max_{k<j} ( max(M_k - oe_ins, 0) + k*e_ins ) - (j-1)*e_ins .
-// Each lane owns CPL adjacent query columns in registers (H and E rows never touch memory); one row
-// = local work + one wavefront exclusive max-scan + three wavefront reductions (row max with last
-// column, first / last non-zero cell for the band trimming of ksw.c:466-469).  Rows stay sequential,
-// which keeps band trimming, z-drop (ksw.c:458-464) and every tie rule exactly as in the reference.
+// Each lane owns 1..CPL adjacent query columns in registers -- the fewest that hold the flank -- (H and E rows
+// never touch memory); one row = local work + one wavefront exclusive max-scan + a max reduction (row max with
+// last column) + a ballot (first / last non-zero cell for the band trimming of ksw.c:466-469); the band and all
+// row control are wavefront-uniform and run on the scalar unit.  Rows stay sequential, which keeps band
+// trimming, z-drop (ksw.c:458-464) and every tie rule exactly as in the reference.
 // Integer DP, no dense contraction: MFMA is not applicable.
+//
+// Two hand-offs keep one read's serial work from setting the duration of the launch: k_extend_spec extends the best
+// seed of every chain of many-chain reads ahead of time (one wavefront per chain), and dedup sorts long region
+// lists with a wavefront rank sort whenever no two keys tie (otherwise with the exact one-lane introsort).
 //
 // The per-seed control flow (containment skip bwamem.c:678-713, band doubling bwamem.c:730-741,
 // clip-vs-to-end choice bwamem.c:743-749) is scalar and uniform across the wavefront; tests over

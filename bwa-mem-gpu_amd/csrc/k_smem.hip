@@ -2,11 +2,13 @@
 //
 // The algorithm is a long chain of dependent bwt_extend calls (bwt.c:262), each a random 64-byte
 // gather (two when the interval straddles an Occ block).  A single read exposes almost no memory-level
-// parallelism and ~1 us of HBM latency per step must be hidden, so the kernel packs 8 reads into one
-// wavefront: a *group* of 8 lanes owns one read (one quad per Occ block, see fmi_dev.h) and runs it
-// as an explicit state machine whose every transition issues exactly one bwt_extend.  All groups of
-// a wavefront therefore reach the extend call site together and their gathers are in flight together
-// (16 x 64 B per wavefront-step).  Groups pull reads from a global work queue.
+// parallelism and ~1-2 us of loaded HBM latency per step must be hidden, so a wavefront carries many reads:
+// a *group* of G lanes owns one read and runs it as an explicit state machine whose every transition
+// issues exactly one bwt_extend.  All groups of a wavefront therefore reach the extend call site together
+// and their gathers are in flight together.  G = 1 (default: one read per lane, the lane fetches and counts
+// its own 64-byte blocks, 128 gathers in flight per wavefront-step), 2 (pair), 4 (quad: 16 B per lane of each
+// block) or 8 (one quad per block); see fmi_dev.h.  Groups pull reads from a global work queue.  Reads that turn
+// out to need thousands of steps are handed to k_smem_heavy (below), pass 3 runs in k_smem3, the sort in k_intv_sort.
 //
 // Per-read state machine (states cite the code they restate):
 //   pass 1  bwamem.c:144-154   for x: bwt_smem1(x, min_intv=1)        FWD (bwt.c:304-320) then BWD (bwt.c:326-345)
