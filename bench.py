@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--sub-ppm", type=int, default=10000, help="substitution errors per million bases (configs[4]: 50000)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BWAHIP_BENCH_CPU_READS", "200000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="exploratory: split the batch into this many sub-batches, each with its own context and stream, run "
+                         "concurrently (stages of different sub-batches overlap; per-kernel timings then overlap too)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,9 +106,36 @@ def main():
     codes = bw.NT4[reads.reshape(-1)]
     off = np.arange(args.reads + 1, dtype=np.int64) * args.read_len
     log(f"rank {rank}: {args.reads} reads generated")
-    ctx.batch_upload(codes, off)
-    log("batch uploaded")
     opt = bw.default_opt()
+    lanes = None
+    if args.lanes > 1:
+        # sub-batches: contexts that adopt one shared copy of the index (bwahip_init_device), one host thread each
+        from concurrent.futures import ThreadPoolExecutor
+        meta, arrays = tp.load_index_arrays(prefix)
+        shared = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in arrays.items()}
+        torch.cuda.synchronize()
+        lanes = [bw.Context.from_device_arrays(meta, shared["bwt"].data_ptr(), shared["sa"].data_ptr(), shared["pac"].data_ptr(), local_rank)
+                 for _ in range(args.lanes)]
+        per = (args.reads + args.lanes - 1) // args.lanes
+        for i, lc in enumerate(lanes):
+            b0, b1 = i * per, min(args.reads, (i + 1) * per)
+            lc.batch_upload(codes[b0 * args.read_len:b1 * args.read_len], off[b0:b1 + 1] - off[b0])
+        pool = ThreadPoolExecutor(args.lanes)
+
+        class Lanes:                                    # same surface as one context for the loop below
+            def batch_run(self, o):
+                return list(pool.map(lambda lc: lc.batch_run(o), lanes))[0]
+
+            def counters(self):
+                tot = None
+                for lc in lanes:
+                    cs = lc.counters()
+                    tot = cs if tot is None else {k: (max(tot[k], v) if k.endswith("_max") or k.startswith("max_") else tot[k] + v) for k, v in cs.items()}
+                return tot
+        ctx = Lanes()
+    else:
+        ctx.batch_upload(codes, off)
+    log("batch uploaded")
 
     def sync_all():
         torch.cuda.synchronize()
@@ -148,7 +178,7 @@ def main():
             "config": {"workload": f"{args.reads} synthetic {args.read_len} bp SE reads ({args.sub_ppm / 10000:g}% substitutions) per GPU vs "
                                    f"{args.genome_mbp} Mbp synthetic genome with repeat families (GRCh38 not available offline); "
                                    "BASELINE configs[1] shape",
-                       "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
+                       "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp, "lanes": args.lanes,
                        "stages": ["k_smem(passes 1-2)+k_smem_heavy+k_smem3(pass 3)+k_intv_sort", "k_seeds", "k_chain", "k_extend_spec+k_extend(+dedup/patch)"],
                        "output": "mem_alnreg_v per read resident in HBM (== mem_align1_core)",
                        "index_build_s": round(t_index, 1), "index_broadcast_s": round(t_bcast, 2)},
