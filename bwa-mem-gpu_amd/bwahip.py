@@ -91,6 +91,9 @@ def lib():
     vp, i64p, u64p, ip = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)
     L.bwahip_version.restype = C.c_char_p
     L.bwahip_opt_init.argtypes = [C.POINTER(Opt)]
+    L.bwahip_opt_fill_scmat.argtypes = [C.POINTER(Opt)]
+    L.bwahip_ctx_tune.argtypes = [vp, C.c_char_p, C.c_int]
+    L.bwahip_kat_ksw_align.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.bwahip_init_from_files.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
@@ -205,7 +208,12 @@ class Context:
         C.CDLL(None).free(out)
         return parse_records(words)
 
-    def process_seqs(self, names, seqs, quals=None, opt=None, n_processed=0):
+    def tune(self, **kw):
+        """Set hand-off thresholds of the heavy-read kernels (bwahip_ctx_tune): intv_cap, smem_lanes, heavy_mult, ..."""
+        for k, v in kw.items():
+            _check(lib().bwahip_ctx_tune(self._h, k.encode(), int(v)), f"bwahip_ctx_tune({k})")
+
+    def process_seqs(self, names, seqs, quals=None, opt=None, n_processed=0, pes0=None, comments=None):
         """mem_process_seqs: list of names / ASCII reads (/ quals) -> list of SAM text (bytes) per read."""
         opt = opt or default_opt()
         n = len(seqs)
@@ -216,10 +224,10 @@ class Context:
             keep.append(sb)
             arr[i].l_seq, arr[i].id = len(seqs[i]), i
             arr[i].name = bytes(names[i])
-            arr[i].comment = None
+            arr[i].comment = bytes(comments[i]) if comments is not None and comments[i] is not None else None
             arr[i].seq = C.cast(sb, C.POINTER(C.c_char))
             arr[i].qual = bytes(quals[i]) if quals is not None else None
-        _check(lib().bwahip_process_seqs(self._h, C.byref(opt), n_processed, n, arr, None), "bwahip_process_seqs")
+        _check(lib().bwahip_process_seqs(self._h, C.byref(opt), n_processed, n, arr, pes0), "bwahip_process_seqs")
         libc = C.CDLL(None)
         libc.free.argtypes = [C.c_void_p]
         out = []
@@ -268,6 +276,17 @@ class Context:
         out = np.zeros((len(params), 6), dtype=np.int32)
         _check(lib().bwahip_kat_ksw_extend(self._h, len(params), params.ctypes.data, q.ctypes.data, qoff.ctypes.data, t.ctypes.data,
                                            toff.ctypes.data, out.ctypes.data), "bwahip_kat_ksw_extend")
+        return out
+
+    def kat_ksw_align(self, params, q, qoff, t, toff, mat=None):
+        """ksw_align2 on the device; params n x 8 (qlen, tlen, xtra, o_del, e_del, o_ins, e_ins, 0) -> n x 7."""
+        params = np.ascontiguousarray(params, dtype=np.int32)
+        q, t = np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8)
+        qoff, toff = np.ascontiguousarray(qoff, dtype=np.int64), np.ascontiguousarray(toff, dtype=np.int64)
+        out = np.zeros((len(params), 7), dtype=np.int32)
+        m = np.ascontiguousarray(mat, dtype=np.int8) if mat is not None else None
+        _check(lib().bwahip_kat_ksw_align(self._h, len(params), params.ctypes.data, m.ctypes.data if m is not None else None, q.ctypes.data,
+                                          qoff.ctypes.data, t.ctypes.data, toff.ctypes.data, out.ctypes.data), "bwahip_kat_ksw_align")
         return out
 
     def kat_extend(self, ik3, is_back):

@@ -169,9 +169,25 @@ struct ExtLaunch {
 	// >= spec_min_chains chains (spec_regs == nullptr: off)
 	DevReg *spec_regs; int2 *spec_items; int *spec_n; int spec_min_chains;
 	int rank_sort_min;                           // dedup: lists at least this long try the wavefront rank sort first (shorter: one-lane introsort hides behind other wavefronts)
+	int *redo_list, *redo_n;                     // reads k_extend hands to k_extend_big (reference window beyond the LDS window)
+	uint8_t *big_t;                              // BWAHIP_EXT_BIG_GRID slabs of BWAHIP_EXT_BIG_T + 64 bytes
+	int lds_window;                              // largest reference window k_extend keeps in LDS (<= its compiled MAXT)
 };
+constexpr int BWAHIP_EXT_BIG_GRID = 128, BWAHIP_EXT_BIG_T = 1 << 16;
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
 int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st);
+
+// K3b: mem_flt_chained_seeds on the chains k_chain / k_chain_flt left (k_seedsw.hip)
+struct SeedSwLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const uint8_t *seq; const int64_t *off;
+	const int64_t *seed_base; DevChain *chains; DevSeed *chain_seeds; const int *chain_n; const int *kept_seeds;
+	const double *logtab;                        // log(i) for i < BWAHIP_LOGTAB_N, computed by the host's libm
+};
+int launch_seed_sw(const SeedSwLaunch &a, hipStream_t st);
+int launch_kat_align(const DevOpt &opt, int n, int byte_mode, const int *items, const int *params, const uint8_t *q, const int64_t *qoff,
+                     const uint8_t *t, const int64_t *toff, uint8_t *wsp, size_t wsp_stride, int *out7, hipStream_t st);
+constexpr int BWAHIP_LOGTAB_N = 65536;
 
 int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff,
                    int *out6, hipStream_t st);

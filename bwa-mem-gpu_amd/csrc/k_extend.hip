@@ -434,7 +434,7 @@ __device__ __forceinline__ void rs_introsort(const RegSort c, int n, int *a, int
 // Window of the reference any seed of the chain could reach (bwamem.c:649-664), clamped to the contig of the first
 // seed as bns_fetch_seq does (bntseq.c:426), loaded into LDS as one base per byte.  false: window larger than MAXT.
 __device__ __forceinline__ bool chain_window(const DevIndex &ix, const DevOpt &opt, const DevSeed *seeds, int n, int l_query,
-                                             uint8_t *s_t, int l, int64_t &rmax0_out, int &tl_all_out)
+                                             uint8_t *s_t, int t_cap, int l, int64_t &rmax0_out, int &tl_all_out)
 {
 	const int64_t l_pac = ix.l_pac;
 	int64_t rmax0 = l_pac << 1, rmax1 = 0;
@@ -462,7 +462,7 @@ __device__ __forceinline__ bool chain_window(const DevIndex &ix, const DevOpt &o
 	}
 	const int tl_all = (int)(rmax1 - rmax0);
 	rmax0_out = rmax0; tl_all_out = tl_all;
-	if (tl_all > MAXT) return false;
+	if (tl_all > t_cap) return false;
 	__syncthreads();
 	for (int i = l; i < tl_all; i += 64) s_t[i] = (uint8_t)ref_base(ix, rmax0 + i);
 	return true;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_exten
 		const int n = ch.n;
 		if (n == 0) continue;
 		int64_t rmax0; int tl_all;
-		if (!chain_window(ix, opt, seeds, n, l_query, s_t, l, rmax0, tl_all)) continue;   // k_extend reports the error
+		if (!chain_window(ix, opt, seeds, n, l_query, s_t, MAXT, l, rmax0, tl_all)) continue;   // k_extend hands the read to the large-window variant
 		// the seed k_extend takes first: largest (score, index) (bwamem.c:669-674)
 		long long best = -1;
 		for (int i = l; i < n; i += 64) { const long long key = (long long)seeds[i].score << 32 | i; best = key > best ? key : best; }
@@ -587,14 +587,16 @@ __global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *it
 	for (int ci = 0; ci < nc; ++ci) items[base + ci] = make_int2(r, ci);
 }
 
-template <int CPL>
-__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_extend(ExtLaunch a)
+// One read: all mem_chain2aln calls, then mem_sort_dedup_patch.  s_t holds the reference window of the current chain: LDS
+// (T_CAP = MAXT) in k_extend; a read with a chain window or a patch window beyond that is handed over (redo list) to
+// k_extend_big, the same code with the window in a global-memory slab of BIG_T bases (tandem repeats: a chain may drift
+// by up to opt.w per merged seed, bwamem.c:203-217, so the window has no small bound; a wide -w widens it too).
+constexpr int BIG_T = BWAHIP_EXT_BIG_T;
+template <int CPL, bool BIGT>
+__device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uint8_t *s_q, uint8_t *s_t, int8_t *s_mat, int *s_stk)
 {
-	__shared__ uint8_t s_q[MAXQ + 8];
-	__shared__ uint8_t s_t[MAXT + 8];
-	__shared__ int8_t s_mat[32];
-	__shared__ int s_stk[3 * 80];
-	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x, l = lane();   // heavy reads are scheduled first (k_order)
+	const int T_CAP = BIGT ? BIG_T : (a.lds_window < MAXT ? a.lds_window : MAXT);   // lds_window: test knob, forces the hand-over onto ordinary reads
+	const int l = lane();
 	const DevOpt &opt = a.opt;
 	const DevIndex &ix = a.ix;
 	const int l_query = (int)(a.off[r + 1] - a.off[r]);
@@ -602,13 +604,14 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_exten
 	const int64_t sb = a.seed_base[r], rb0 = a.reg_base[r];
 	const int n_chains = a.chain_n[r];
 	const int64_t l_pac = ix.l_pac;
-	const bool use_spec = a.spec_regs && n_chains >= a.spec_min_chains;
+	const bool use_spec = !BIGT && a.spec_regs && n_chains >= a.spec_min_chains;
 	DevReg *av = a.regs + rb0;                                  // the read's region list (av of bwamem.c:639)
 	int *srt = a.srt + 2 * sb;                                  // [0..n): seed index in ascending (score,idx) order; [n..2n): skipped flag
 	int n_av = 0;
 	Work wk = { 0, 0, 0 };
 	const unsigned long long t_0 = wall_clock64();
 	Sw sw; sw.mat = s_mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins;
+	__syncthreads();
 	if (l < 25) s_mat[l] = opt.mat[l];
 	sw.mx = wmax(l < 25 ? (int)opt.mat[l] : 0); if (sw.mx < 0) sw.mx = 0;
 	for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
@@ -620,7 +623,14 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_exten
 		const int n = ch.n;
 		if (n == 0) continue;
 		int64_t rmax0; int tl_all;
-		if (!chain_window(ix, opt, seeds, n, l_query, s_t, l, rmax0, tl_all)) { if (l == 0) atomicExch(a.err, 3); break; }
+		if (!chain_window(ix, opt, seeds, n, l_query, s_t, T_CAP, l, rmax0, tl_all)) {
+			if (l == 0) {
+				if (BIGT) { atomicExch(a.err, 3); atomicExch(a.err + 1, r); }          // window beyond BIG_T bases
+				else a.redo_list[atomicAdd(a.redo_n, 1)] = r;                          // k_extend_big redoes the read
+				a.reg_n[r] = 0;
+			}
+			return;
+		}
 		// ---- seeds in ascending (score<<32|index) order (bwamem.c:669-672; keys are unique, any sort does)
 		for (int i = l; i < n; i += 64) {
 			const int sc = seeds[i].score;
@@ -755,7 +765,14 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_exten
 							int gsc = 0;
 							bool have = !(lq <= 0 || grb >= gre || (grb < l_pac && gre > l_pac));
 							const int rlen = (int)(gre - grb);
-							if (have && rlen > MAXT) { if (l == 0) atomicExch(a.err, 4); have = false; }
+								if (have && rlen > T_CAP) {                      // patch window beyond the LDS window: same hand-over
+									if (l == 0) {
+										if (BIGT) { atomicExch(a.err, 4); atomicExch(a.err + 1, r); }
+										else a.redo_list[atomicAdd(a.redo_n, 1)] = r;
+										a.reg_n[r] = 0;
+									}
+									return;
+								}
 							if (have) {
 								__syncthreads();
 								for (int t = l; t < rlen; t += 64) s_t[t] = (uint8_t)ref_base(ix, grb + t);
@@ -864,6 +881,32 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_exten
 	}
 }
 
+template <int CPL>
+__global__ __launch_bounds__(64, (CPL <= 3 ? 5 : CPL == 4 ? 4 : 1)) void k_extend(ExtLaunch a)
+{
+	__shared__ uint8_t s_q[MAXQ + 8];
+	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ int8_t s_mat[32];
+	__shared__ int s_stk[3 * 80];
+	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;   // heavy reads are scheduled first (k_order)
+	extend_read<CPL, false>(a, r, s_q, s_t, s_mat, s_stk);
+}
+
+// the reads k_extend handed over (reference window beyond LDS): window in this workgroup's global slab
+template <int CPL>
+__global__ __launch_bounds__(64) void k_extend_big(ExtLaunch a)
+{
+	__shared__ uint8_t s_q[MAXQ + 8];
+	__shared__ int8_t s_mat[32];
+	__shared__ int s_stk[3 * 80];
+	uint8_t *s_t = a.big_t + (size_t)blockIdx.x * (BIG_T + 64);
+	const int n_redo = *a.redo_n;
+	for (int it = (int)blockIdx.x; it < n_redo; it += (int)gridDim.x) {
+		extend_read<CPL, true>(a, a.redo_list[it], s_q, s_t, s_mat, s_stk);
+		__syncthreads();
+	}
+}
+
 // Scheduling aid: reads with many seeds to extend go to the front of the launch order so that the long
 // ones start first and the short ones fill in behind them (the order has no effect on results).
 __global__ void k_order(int n, const int *kept_seeds, int *perm, int *counts)
@@ -932,5 +975,7 @@ int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_extend<4>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend<5>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else hipLaunchKernelGGL(k_extend<11>, dim3(a.n_reads), dim3(64), 0, st, a);
+	// reads whose reference window exceeded the LDS window (none on ordinary data): one generic instantiation
+	hipLaunchKernelGGL(k_extend_big<11>, dim3(BWAHIP_EXT_BIG_GRID), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

@@ -96,10 +96,35 @@ int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st)
 }
 } // namespace
 
-static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec", "k_smem3", "k_intv_sort" };
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec", "k_smem3", "k_intv_sort", "k_seed_sw" };
+
+// Tuning knobs (hand-off thresholds of the heavy-read kernels).  Read from the environment ONCE, when the context is
+// created; bwahip_ctx_tune changes them afterwards (tests force every hand-off kernel onto ordinary reads that way).
+struct Knobs {
+	int intv_cap = 96;          // BWAHIP_INTV_CAP: initial per-read interval capacity (grown on overflow)
+	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
+	int heavy_mult = 10;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never)
+	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which k_chain_big takes the read (< 0: off)
+	int rank_sort_min = 192;    // BWAHIP_RANK_SORT_MIN: dedup lists at least this long try the wavefront rank sort
+	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
+	int ext_lds_window = 1 << 30;   // BWAHIP_EXT_LDS_WINDOW: reference windows above this go to k_extend_big (tests; default = the compiled LDS window)
+	int verbose = 0;            // BWAHIP_VERBOSE
+	const char *dump_ext = nullptr;   // BWAHIP_DUMP_EXT (diagnostic)
+	void from_env()
+	{
+		auto geti = [](const char *k, int &v) { if (const char *e = getenv(k)) v = atoi(e); };
+		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult);
+		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window);
+		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
+		dump_ext = getenv("BWAHIP_DUMP_EXT");
+		if (intv_cap < 2) intv_cap = 2;
+	}
+};
 
 struct bwahip_ctx {
-	bool external_index = false;         // index arrays live in caller-owned HBM (bwahip_init_device)
+	bool external_index = false;
+	Knobs knobs;
+	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
 	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
@@ -115,11 +140,11 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big;
-	int intv_cap = 96;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t;
+	int intv_cap = 96;                   // current capacity (starts at knobs.intv_cap, grows on overflow)
 	int64_t total_seeds = 0, total_regs = 0;
-	hipEvent_t ev[16];
-	float last_ms[12];
+	hipEvent_t ev[24];
+	float last_ms[24];
 };
 
 DevOpt make_dev_opt(const bwahip_opt_t *o)
@@ -167,6 +192,14 @@ void bwahip_opt_init(bwahip_opt_t *o)        // mem_opt_init, bwamem.c:74-110
 		for (int j = 0; j < 5; ++j) o->mat[k++] = (i == 4 || j == 4) ? -1 : i == j ? o->a : -o->b;
 }
 
+void bwahip_opt_fill_scmat(bwahip_opt_t *o)   // bwa_fill_scmat, bwa.c:249: call after changing a / b
+{
+	if (!o) return;
+	int k = 0;
+	for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) o->mat[k++] = i == j ? o->a : -o->b; o->mat[k++] = -1; }
+	for (int j = 0; j < 5; ++j) o->mat[k++] = -1;
+}
+
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
 {
 	int rc = b.ensure(bytes ? bytes : 16);
@@ -185,6 +218,14 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
 	int rc;
+	c->knobs.from_env();
+	c->intv_cap = c->knobs.intv_cap;
+	{
+		std::vector<double> lt(BWAHIP_LOGTAB_N);
+		for (int i = 0; i < BWAHIP_LOGTAB_N; ++i) lt[i] = i ? log((double)i) : 0.;   // glibc's log: the values the reference computes on the host
+		if ((rc = upload(c->d_logtab, lt.data(), lt.size() * 8, c->stream))) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
 	if (c->external_index) {             // adopt caller-owned device arrays (e.g. received over RCCL)
 		c->d_bwt.p = bwt->bwt; c->d_sa.p = bwt->sa; c->d_pac.p = (void*)pac;
 	} else {
@@ -272,7 +313,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big };
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -290,7 +331,59 @@ const bwahip_bns_t *bwahip_bns(const bwahip_ctx *c) { return c ? &c->host.bns : 
 const bwahip_bwt_t *bwahip_bwt(const bwahip_ctx *c) { return c ? &c->host.bwt : nullptr; }
 const uint8_t *bwahip_pac(const bwahip_ctx *c) { return c ? c->host.pac : nullptr; }
 
+int bwahip_ctx_tune(bwahip_ctx *c, const char *key, int value)
+{
+	if (!c || !key) return BWAHIP_EINVAL;
+	Knobs &k = c->knobs;
+	if (!strcmp(key, "intv_cap")) { k.intv_cap = value < 2 ? 2 : value; c->intv_cap = k.intv_cap; }
+	else if (!strcmp(key, "smem_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return BWAHIP_EINVAL; k.smem_lanes = value; }
+	else if (!strcmp(key, "heavy_mult")) k.heavy_mult = value;
+	else if (!strcmp(key, "chain_big_min")) k.chain_big_min = value;
+	else if (!strcmp(key, "rank_sort_min")) k.rank_sort_min = value;
+	else if (!strcmp(key, "spec_min_chains")) k.spec_min_chains = value;
+	else if (!strcmp(key, "ext_lds_window")) k.ext_lds_window = value < 1 ? 1 : value;
+	else if (!strcmp(key, "verbose")) k.verbose = value;
+	else return BWAHIP_EINVAL;
+	return 0;
+}
+
 // ------------------------------------------------------------------ known-answer helpers
+int bwahip_kat_ksw_align(bwahip_ctx *c, int n, const int *params, const int8_t *mat25, const uint8_t *q, const int64_t *qoff,
+                         const uint8_t *t, const int64_t *toff, int *out7)
+{
+	if (!c || n < 0 || (n && (!params || !q || !qoff || !t || !toff || !out7))) return BWAHIP_EINVAL;
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(c->device));
+	bwahip_opt_t o; bwahip_opt_init(&o);
+	if (mat25) memcpy(o.mat, mat25, 25);
+	DevOpt dopt = make_dev_opt(&o);
+	std::vector<int> items[2];                               // [0] word kernel, [1] byte kernel (KSW_XBYTE)
+	size_t stride = 0;
+	for (int i = 0; i < n; ++i) {
+		const int qlen = params[8*i], tlen = params[8*i+1];
+		if (qlen < 0 || tlen < 0 || qlen > (1 << 20) || tlen > (1 << 20)) return BWAHIP_EINVAL;
+		items[(params[8*i+2] & 0x10000) ? 1 : 0].push_back(i);
+		const size_t cells = (size_t)(qlen + 15) / 16 * 16;
+		stride = std::max(stride, 5 * cells + 16 + 8 * cells + 2 * (size_t)tlen + 16);
+	}
+	stride = (stride + 15) & ~(size_t)15;
+	DevBuf dp, dq, dqo, dt, dto, dout, dit, dw; int rc;
+	if ((rc = upload(dp, params, (size_t)n * 32, c->stream)) || (rc = upload(dq, q, (size_t)qoff[n], c->stream)) || (rc = upload(dqo, qoff, (size_t)(n + 1) * 8, c->stream)) ||
+	    (rc = upload(dt, t, (size_t)toff[n], c->stream)) || (rc = upload(dto, toff, (size_t)(n + 1) * 8, c->stream)) || (rc = dout.ensure((size_t)n * 28)) ||
+	    (rc = dw.ensure(stride * (size_t)n))) goto done;
+	for (int m = 0; m < 2 && !rc; ++m) {
+		if (items[m].empty()) continue;
+		if ((rc = upload(dit, items[m].data(), items[m].size() * 4, c->stream))) break;
+		rc = launch_kat_align(dopt, (int)items[m].size(), m, dit.as<int>(), dp.as<int>(), dq.as<uint8_t>(), dqo.as<int64_t>(), dt.as<uint8_t>(), dto.as<int64_t>(),
+		                      dw.as<uint8_t>(), stride, dout.as<int>(), c->stream);
+		if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	}
+	if (!rc && hipMemcpy(out7, dout.p, (size_t)n * 28, hipMemcpyDeviceToHost) != hipSuccess) rc = BWAHIP_ENODEV;
+done:
+	dp.release(); dq.release(); dqo.release(); dt.release(); dto.release(); dout.release(); dit.release(); dw.release();
+	return rc;
+}
+
 int bwahip_kat_occ4(bwahip_ctx *c, int n, const uint64_t *k, uint64_t *out)
 {
 	if (!c || n < 0) return BWAHIP_EINVAL;
@@ -361,7 +454,7 @@ const char *bwahip_kernel_name(int i) { return i >= 0 && i < bwahip_n_kernels() 
 
 static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 {
-	const bool verbose = getenv("BWAHIP_VERBOSE") != nullptr;
+	const bool verbose = c->knobs.verbose != 0;
 #define STAGE_LOG(name) do { if (verbose) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bwahip] %s done (%s)\n", name, hipGetErrorString(hipGetLastError())); fflush(stderr); } } while (0)
 	const int n = c->n_reads;
 	if (n == 0) return 0;
@@ -371,10 +464,9 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	unsigned int *queue = (unsigned int*)(counters + (size_t)CNT_SLOTS * CNT_N);
 	int *err = (int*)(queue + 4);
 	int rc;
-	if (getenv("BWAHIP_INTV_CAP")) c->intv_cap = std::max(2, atoi(getenv("BWAHIP_INTV_CAP")));   // tests: start small to exercise the re-run
 	for (int attempt = 0; attempt < 8; ++attempt) {
 		const int cap = c->intv_cap, lcap = c->max_len + 2;
-		const int G = getenv("BWAHIP_SMEM_LANES") ? atoi(getenv("BWAHIP_SMEM_LANES")) : 1;   // lanes per read in k_smem (1, 2, 4 or 8)
+		const int G = c->knobs.smem_lanes;                       // lanes per read in k_smem (1, 2, 4 or 8)
 		const int groups = smem_default_groups(G);
 		if ((rc = c->d_intv.ensure((size_t)n * cap * sizeof(DevIntv))) || (rc = c->d_raw.ensure((size_t)n * cap * sizeof(DevIntv))) || (rc = c->d_raw_n.ensure((size_t)n * 4))) return rc;
 		if ((rc = c->d_intv_n.ensure((size_t)n * 4)) || (rc = c->d_seed_cnt.ensure((size_t)n * 4)) || (rc = c->d_lrep.ensure((size_t)n * 4))) return rc;
@@ -392,7 +484,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		sl.seq4 = c->d_seq4.as<uint64_t>();
 		if (attempt == 0 && (rc = launch_pack4(sl, c->stream))) return rc;
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
-		const int heavy_mult = getenv("BWAHIP_HEAVY_MULT") ? atoi(getenv("BWAHIP_HEAVY_MULT")) : 10;   // x read length; 0 = never hand off
+		const int heavy_mult = c->knobs.heavy_mult;              // x read length; 0 = never hand off
 		if ((rc = c->d_smem_heavy.ensure((size_t)n * 4))) return rc;
 		sl.heavy_list = c->d_smem_heavy.as<int>(); sl.heavy_n = queue + 1; sl.heavy_mult = heavy_mult; sl.worst_n = (int*)(queue + 2);
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -417,7 +509,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		HIP_TRY(hipMemcpyAsync(&h_worst, queue + 2, 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (h_err) { fprintf(stderr, "[bwahip] k_smem reported an internal inconsistency\n"); return BWAHIP_EINTERNAL; }
-		if (const char *dump_ext = getenv("BWAHIP_DUMP_EXT")) {   // diagnostic: per-read bwt_extend counts as int32
+		if (const char *dump_ext = c->knobs.dump_ext) {   // diagnostic: per-read bwt_extend counts as int32
 			std::vector<int> h_e(n);
 			HIP_TRY(hipMemcpy(h_e.data(), c->d_lrep.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 			if (FILE *fp = fopen(dump_ext, "wb")) { fwrite(h_e.data(), 4, n, fp); fclose(fp); }
@@ -458,7 +550,7 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		cl.counters = counters;
 		if ((rc = c->d_flt.ensure(T * 32)) || (rc = c->d_heavy.ensure((size_t)(n + 4) * 4))) return rc;
 		cl.flt = c->d_flt.as<int>(); cl.heavy_list = c->d_heavy.as<int>() + 4; cl.heavy_count = c->d_heavy.as<int>();
-		const int big_min = getenv("BWAHIP_CHAIN_BIG_MIN") ? atoi(getenv("BWAHIP_CHAIN_BIG_MIN")) : 512;   // seeds; < 0 = off
+		const int big_min = c->knobs.chain_big_min;              // seeds; < 0 = off
 		if (big_min >= 0) {
 			if ((rc = c->d_chain_big.ensure((size_t)(n + 4) * 4))) return rc;
 			HIP_TRY(hipMemsetAsync(c->d_chain_big.p, 0, 16, c->stream));
@@ -471,6 +563,18 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = launch_chain_flt(cl, c->stream))) return rc;
 		STAGE_LOG("k_chain");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
+		// ---- K3b: mem_flt_chained_seeds (bwamem.c:605).  With -W 0 it returns at its first test for every read of 2..700
+		// bases (5.5 ln l > 0.05 l there), so the launch is skipped; the kernel itself repeats the test per read.
+		if (opt->min_chain_weight != 0 || c->max_len > 700) {
+			SeedSwLaunch ss;
+			memset(&ss, 0, sizeof ss);
+			ss.ix = c->ix; ss.opt = dopt; ss.n_reads = n; ss.seq = c->d_seq.as<uint8_t>(); ss.off = c->d_off.as<int64_t>();
+			ss.seed_base = c->d_seed_base.as<int64_t>(); ss.chains = c->d_chains.as<DevChain>(); ss.chain_seeds = c->d_chain_seeds.as<DevSeed>();
+			ss.chain_n = c->d_chain_n.as<int>(); ss.kept_seeds = c->d_kept_seeds.as<int>(); ss.logtab = c->d_logtab.as<double>();
+			if ((rc = launch_seed_sw(ss, c->stream))) return rc;
+			STAGE_LOG("k_seed_sw");
+		}
+		if (timed) HIP_TRY(hipEventRecord(c->ev[14], c->stream));
 		if ((rc = launch_scan(c->d_kept_seeds.as<int>(), c->d_reg_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 		if (timed) HIP_TRY(hipEventRecord(c->ev[7], c->stream));
 		int64_t total_regs = 0;
@@ -492,8 +596,11 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = c->d_perm.ensure((size_t)(n + 4) * 4))) return rc;
 		el.kept_seeds = c->d_kept_seeds.as<int>(); el.perm = c->d_perm.as<int>() + 4; el.perm_counts = c->d_perm.as<int>();
 		el.counters = counters; el.err = err;
-		el.rank_sort_min = getenv("BWAHIP_RANK_SORT_MIN") ? atoi(getenv("BWAHIP_RANK_SORT_MIN")) : 192;
-		const int spec_min = getenv("BWAHIP_SPEC_MIN_CHAINS") ? atoi(getenv("BWAHIP_SPEC_MIN_CHAINS")) : 16;   // 0 = no ahead-of-time extension
+		if ((rc = c->d_redo.ensure((size_t)(n + 4) * 4)) || (rc = c->d_big_t.ensure((size_t)BWAHIP_EXT_BIG_GRID * (BWAHIP_EXT_BIG_T + 64)))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 16, c->stream));
+		el.redo_n = c->d_redo.as<int>(); el.redo_list = c->d_redo.as<int>() + 4; el.big_t = c->d_big_t.as<uint8_t>(); el.lds_window = c->knobs.ext_lds_window;
+		el.rank_sort_min = c->knobs.rank_sort_min;
+		const int spec_min = c->knobs.spec_min_chains;           // 0 = no ahead-of-time extension
 		if (spec_min > 0) {
 			if ((rc = c->d_spec_regs.ensure(T * sizeof(DevReg))) || (rc = c->d_spec_items.ensure(T * 8 + 16))) return rc;
 			el.spec_regs = c->d_spec_regs.as<DevReg>(); el.spec_n = c->d_spec_items.as<int>(); el.spec_items = (int2*)(c->d_spec_items.as<int>() + 4);
@@ -507,9 +614,15 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 		if ((rc = launch_extend(el, c->max_len, c->stream))) return rc;
 		STAGE_LOG("k_extend");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[9], c->stream));
-		HIP_TRY(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, c->stream));
+		int h_err2[2] = { 0, 0 };
+		HIP_TRY(hipMemcpyAsync(h_err2, err, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
-		if (h_err) { fprintf(stderr, "[bwahip] extension kernel reported code %d (reference window or read beyond compiled limits)\n", h_err); return h_err >= 3 ? BWAHIP_ECAPACITY : BWAHIP_EINTERNAL; }
+		h_err = h_err2[0];
+		if (h_err == 3 || h_err == 4) {
+			fprintf(stderr, "[bwahip] read %d of the batch: a chain's reference window exceeds %d bases (%s)\n", h_err2[1], BWAHIP_EXT_BIG_T, h_err == 3 ? "extension" : "region patch");
+			return BWAHIP_ECAPACITY;
+		}
+		if (h_err) { fprintf(stderr, "[bwahip] extension kernel reported code %d\n", h_err); return BWAHIP_EINTERNAL; }
 		if (timed) {
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[1], c->ev[10], c->ev[2]));
@@ -518,7 +631,8 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[9], c->ev[13], c->ev[10]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[6]));
-			HIP_TRY(hipEventElapsedTime(&c->last_ms[4], c->ev[6], c->ev[7]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[4], c->ev[14], c->ev[7]));
+			HIP_TRY(hipEventElapsedTime(&c->last_ms[10], c->ev[6], c->ev[14]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[5], c->ev[8], c->ev[9]));
 			HIP_TRY(hipEventElapsedTime(&c->last_ms[7], c->ev[11], c->ev[8]));
 		}

@@ -175,6 +175,7 @@ const bwahip_bns_t *bwahip_bns(const bwahip_ctx *ctx);
 const bwahip_bwt_t *bwahip_bwt(const bwahip_ctx *ctx);
 const uint8_t      *bwahip_pac(const bwahip_ctx *ctx);
 void bwahip_opt_init(bwahip_opt_t *opt);     /* mem_opt_init defaults, bwamem.c:74 */
+void bwahip_opt_fill_scmat(bwahip_opt_t *opt);   /* bwa_fill_scmat(opt->a, opt->b, opt->mat), bwa.c:249: call after changing a or b */
 
 /* ---- the hot path ---------------------------------------------------------
  * bwahip_align_batch == kt_for(worker1) of mem_process_seqs (bwamem.c:1232): for every read i it
@@ -224,6 +225,17 @@ int bwahip_kat_sa(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *sa_out);
 int bwahip_kat_extend(bwahip_ctx *ctx, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12_out);
 int bwahip_kat_ksw_extend(bwahip_ctx *ctx, int n, const int *params /*n x 10*/, const uint8_t *q, const int64_t *qoff,
                           const uint8_t *t, const int64_t *toff, int *out6 /*n x 6*/);
+
+/* ksw_align2 (ksw.c:343) on the device, byte or word kernel as xtra's KSW_XBYTE says.  params: n x 8 ints
+ * (qlen, tlen, xtra, o_del, e_del, o_ins, e_ins, 0); mat25 NULL = the default 1/-4 matrix; out7: n x 7
+ * (score, te, qe, score2, te2, tb, qb). */
+int bwahip_kat_ksw_align(bwahip_ctx *ctx, int n, const int *params, const int8_t *mat25, const uint8_t *q, const int64_t *qoff,
+                         const uint8_t *t, const int64_t *toff, int *out7);
+
+/* Tuning knobs of the heavy-read hand-off kernels (tests force each one onto ordinary reads): keys intv_cap,
+ * smem_lanes, heavy_mult, chain_big_min, rank_sort_min, spec_min_chains, ext_lds_window, verbose.  The same knobs are read from the
+ * environment (BWAHIP_<KEY>) once, when the context is created. */
+int bwahip_ctx_tune(bwahip_ctx *ctx, const char *key, int value);
 
 const char *bwahip_version(void);
 

@@ -12,7 +12,13 @@
 #include <zlib.h>
 #include <sys/time.h>
 static double now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + tv.tv_usec * 1e-6; }
+#include <math.h>
 #include "ora.h"
+#define OPT_T ora_opt_t
+#define PES_T ora_pestat_t
+#define OPT_FILL_SCMAT(a, b, mat) ora_fill_scmat((a), (b), (mat))
+#define OPT_LOG(x) log(x)
+#include "opt_parse.h"
 
 /* ---- minimal FASTA/FASTQ reader with kseq.h's field semantics ---- */
 typedef struct { gzFile fp; char *line; size_t m; int peeked; } fq_t;
@@ -124,9 +130,15 @@ static int main_stages(int argc, char **argv)
 	FILE *out;
 	ora_read_t r;
 	int64_t id = 0;
-	if (argc < 4) return 1;
+	optparse_t op;
+	int c;
 	ora_opt_init(&opt);
+	optparse_init(&op, &opt);
+	while ((c = getopt(argc, argv, OPT_GETOPT_STRING)) >= 0) if (optparse_one(&op, c, optarg)) return 1;
+	if (optparse_finish(&op) || optind + 3 > argc) return 1;
+	argv += optind - 1;
 	idx = ora_index_load(argv[1]);
+	if (op.ignore_alt) for (c = 0; c < idx->ref->n_seqs; ++c) idx->ref->anns[c].is_alt = 0;
 	f.fp = gzopen(argv[2], "r");
 	out = fopen(argv[3], "wb");
 	while (fq_read(&f, &r)) {
@@ -168,31 +180,29 @@ static int main_stages(int argc, char **argv)
 static int main_mem(int argc, char **argv)
 {
 	ora_opt_t opt;
-	int c, n, is_pe = 0, fixed_chunk = 0;
+	int c, n;
 	int64_t n_processed = 0;
 	double t_align = 0;
 	ora_index_t *idx;
 	fq_t f1 = { 0, 0, 0, 0 }, f2 = { 0, 0, 0, 0 };
 	ora_read_t *seqs;
+	optparse_t op;
 	ora_opt_init(&opt);
-	while ((c = getopt(argc, argv, "pt:K:a")) >= 0) {
-		if (c == 'p') is_pe = 1;
-		else if (c == 't') opt.n_threads = atoi(optarg);
-		else if (c == 'K') fixed_chunk = atoi(optarg);
-		else if (c == 'a') opt.flag |= ORA_F_ALL;
-	}
-	if (optind + 2 > argc) return 1;
+	optparse_init(&op, &opt);
+	while ((c = getopt(argc, argv, OPT_GETOPT_STRING)) >= 0) if (optparse_one(&op, c, optarg)) return 1;
+	if (optparse_finish(&op) || optind + 2 > argc) return 1;
 	idx = ora_index_load(argv[optind]);
+	if (op.ignore_alt) for (c = 0; c < idx->ref->n_seqs; ++c) idx->ref->anns[c].is_alt = 0;
 	f1.fp = gzopen(argv[optind + 1], "r");
-	if (optind + 2 < argc) { f2.fp = gzopen(argv[optind + 2], "r"); is_pe = 1; }
-	if (is_pe) opt.flag |= ORA_F_PE;
+	if (optind + 2 < argc && !op.smart_pe) { f2.fp = gzopen(argv[optind + 2], "r"); opt.flag |= ORA_F_PE; }
+	strcpy(ora_rg_id, op.rg_id);
 	{
-		int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;   /* fastmap.c:304 */
+		int chunk = op.fixed_chunk > 0 ? op.fixed_chunk : opt.chunk_size * opt.n_threads;   /* fastmap.c:304 */
 		while ((seqs = read_batch(chunk, &n, &f1, f2.fp ? &f2 : 0)) != 0) {
 			int i;
 			if (n == 0) { free(seqs); break; }
-			for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; }     /* stock behaviour without -C */
-			{ double t0 = now_s(); ora_process_seqs(&opt, idx, n_processed, n, seqs, 0); t_align += now_s() - t0; }
+			if (!op.copy_comment) for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; }     /* stock behaviour without -C */
+			{ double t0 = now_s(); ora_process_seqs(&opt, idx, n_processed, n, seqs, op.has_pes0 ? op.pes : 0); t_align += now_s() - t0; }
 			n_processed += n;
 			for (i = 0; i < n; ++i) {
 				if (seqs[i].sam) fputs(seqs[i].sam, stdout);

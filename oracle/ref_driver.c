@@ -18,6 +18,8 @@
  *   katfm  <prefix> <out.bin> <n> <seed>         known answers: occ4/extend/sa
  *   katksw <out.bin> <n> <seed>                  known answers: ksw_extend2 /
  *                                                ksw_global2 / ksw_align2
+ *   katalign <out.bin> <n> <seed>                known answers: ksw_align2 under
+ *                                                other matrices / gap costs / xtra
  *
  * Dump format ("i64 records"): a stream of  [tag:i64][n:i64][n x i64].
  */
@@ -30,6 +32,11 @@ static double now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.t
 KSEQ_DECLARE(gzFile)
 
 extern int bwa_idx_build(const char *fa, const char *prefix, int algo_type, int block_size);
+#define OPT_T mem_opt_t
+#define PES_T mem_pestat_t
+#define OPT_FILL_SCMAT(a, b, mat) bwa_fill_scmat((a), (b), (mat))
+#define OPT_LOG(x) log(x)
+#include "opt_parse.h"
 
 /* ---------------------------------------------------------------- records */
 static void rec_write(FILE *fp, int64_t tag, int64_t n, const int64_t *v)
@@ -46,7 +53,7 @@ static inline void push(i64v *v, int64_t x)
 static inline int64_t f2i(float f) { uint32_t u; memcpy(&u, &f, 4); return (int64_t)u; }
 
 enum { TAG_READ = 100, TAG_INTV = 1, TAG_CHAIN = 2, TAG_CHAIN_FLT = 3, TAG_REGS_PRE = 5, TAG_REGS = 4,
-       TAG_OCC4 = 10, TAG_EXTEND = 11, TAG_SA = 12, TAG_KSW_EXT = 20, TAG_KSW_GLB = 21, TAG_KSW_ALN = 22 };
+       TAG_OCC4 = 10, TAG_EXTEND = 11, TAG_SA = 12, TAG_KSW_EXT = 20, TAG_KSW_GLB = 21, TAG_KSW_ALN = 22, TAG_KSW_ALN2 = 23 };
 
 static void dump_chains(FILE *fp, int64_t tag, int n, const mem_chain_t *a)
 {
@@ -95,35 +102,31 @@ static int main_index(int argc, char **argv)
 static int main_mem(int argc, char **argv)
 {
 	mem_opt_t *opt = mem_opt_init();
-	int c, n, is_pe = 0, fixed_chunk = 0, print_hdr = 0;
+	int c, n;
 	int64_t n_processed = 0;
 	double t_align = 0;
 	bwaidx_t *idx;
 	gzFile f1, f2 = 0;
 	kseq_t *ks, *ks2 = 0;
 	bseq1_t *seqs;
+	optparse_t op;
 	bwa_verbose = 1;
-	while ((c = getopt(argc, argv, "pt:K:Ha")) >= 0) {
-		if (c == 'p') is_pe = 1;
-		else if (c == 't') opt->n_threads = atoi(optarg);
-		else if (c == 'K') fixed_chunk = atoi(optarg);
-		else if (c == 'H') print_hdr = 1;
-		else if (c == 'a') opt->flag |= MEM_F_ALL;
-	}
-	if (optind + 2 > argc) return 1;
+	optparse_init(&op, opt);
+	while ((c = getopt(argc, argv, OPT_GETOPT_STRING)) >= 0) if (optparse_one(&op, c, optarg)) return 1;
+	if (optparse_finish(&op) || optind + 2 > argc) return 1;
 	idx = bwa_idx_load(argv[optind], BWA_IDX_ALL);
 	if (idx == 0) return 1;
+	if (op.ignore_alt) for (c = 0; c < idx->bns->n_seqs; ++c) idx->bns->anns[c].is_alt = 0;
 	f1 = gzopen(argv[optind + 1], "r"); ks = kseq_init(f1);
-	if (optind + 2 < argc) { f2 = gzopen(argv[optind + 2], "r"); ks2 = kseq_init(f2); is_pe = 1; }
-	if (is_pe) opt->flag |= MEM_F_PE;
-	if (print_hdr) bwa_print_sam_hdr(idx->bns, 0);
+	if (optind + 2 < argc && !op.smart_pe) { f2 = gzopen(argv[optind + 2], "r"); ks2 = kseq_init(f2); opt->flag |= MEM_F_PE; }
+	strcpy(bwa_rg_id, op.rg_id);
 	{
-		int chunk = fixed_chunk > 0 ? fixed_chunk : opt->chunk_size * opt->n_threads; /* fastmap.c:304 */
+		int chunk = op.fixed_chunk > 0 ? op.fixed_chunk : opt->chunk_size * opt->n_threads; /* fastmap.c:304 */
 		while ((seqs = bseq_read(chunk, &n, ks, ks2)) != 0) {
 			int i;
 			if (n == 0) { free(seqs); break; }
-			for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; } /* stock: no -C */
-			{ double t0 = now_s(); mem_process_seqs(opt, idx->bwt, idx->bns, idx->pac, n_processed, n, seqs, 0); t_align += now_s() - t0; }
+			if (!op.copy_comment) for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; } /* stock: no -C */
+			{ double t0 = now_s(); mem_process_seqs(opt, idx->bwt, idx->bns, idx->pac, n_processed, n, seqs, op.has_pes0 ? op.pes : 0); t_align += now_s() - t0; }
 			n_processed += n;
 			for (i = 0; i < n; ++i) {
 				if (seqs[i].sam) fputs(seqs[i].sam, stdout);
@@ -149,10 +152,16 @@ static int main_stages(int argc, char **argv)
 	kseq_t *ks;
 	FILE *out;
 	int64_t id = 0;
+	optparse_t op;
+	int c;
 	bwa_verbose = 1;
-	if (argc < 4) return 1;
+	optparse_init(&op, opt);
+	while ((c = getopt(argc, argv, OPT_GETOPT_STRING)) >= 0) if (optparse_one(&op, c, optarg)) return 1;
+	if (optparse_finish(&op) || optind + 3 > argc) return 1;
+	argv += optind - 1;
 	idx = bwa_idx_load(argv[1], BWA_IDX_ALL);
 	if (idx == 0) return 1;
+	if (op.ignore_alt) for (c = 0; c < idx->bns->n_seqs; ++c) idx->bns->anns[c].is_alt = 0;
 	f1 = gzopen(argv[2], "r"); ks = kseq_init(f1);
 	out = fopen(argv[3], "wb");
 	while (kseq_read(ks) >= 0) {
@@ -337,6 +346,54 @@ static int main_katksw(int argc, char **argv)
 	return 0;
 }
 
+/* ksw_align2 (ksw.c:343) beyond the one call shape of katksw: word kernel as mem_seed_sw calls it (KSW_XSTART only,
+ * bwamem.c:601), byte / word kernels with a sub-optimal threshold as mem_matesw does (bwamem_pair.c:165), under several
+ * scoring matrices and gap costs.  Record: qlen tlen xtra o_del e_del o_ins e_ins mat[25] q[qlen] t[tlen] | 7 results. */
+static int main_katalign(int argc, char **argv)
+{
+	static const int ab[4][2] = { {1, 4}, {2, 3}, {1, 1}, {3, 9} };
+	static const int gaps[4][4] = { {6, 1, 6, 1}, {4, 2, 7, 1}, {1, 1, 1, 1}, {16, 1, 16, 1} };
+	FILE *out;
+	int i, n;
+	if (argc < 4) return 1;
+	out = fopen(argv[1], "wb");
+	n = atoi(argv[2]); rng_state = strtoull(argv[3], 0, 10);
+	for (i = 0; i < n; ++i) {
+		const int *sc = ab[rng() % 4], *g = gaps[rng() % 4];
+		int kind = rng() % 3, a = sc[0];
+		int qlen = kind == 0 ? 1 + rng() % 199 : 1 + rng() % 400, tlen, err = rng() % 15, xtra, j;
+		int8_t mat[25];
+		uint8_t *q, *t;
+		i64v v = {0, 0, 0};
+		kswr_t r;
+		if (kind == 0) { tlen = 1 + rng() % 199; xtra = KSW_XSTART; }                       /* mem_seed_sw */
+		else {
+			tlen = qlen + (int)(rng() % 500);
+			xtra = KSW_XSUBO | KSW_XSTART | ((qlen * a < 250) ? KSW_XBYTE : 0) | (19 * a); /* mem_matesw */
+			if (kind == 2 && (rng() & 1)) xtra &= ~KSW_XBYTE;                             /* word kernel on short queries too */
+		}
+		bwa_fill_scmat(a, sc[1], mat);
+		q = malloc(qlen); t = malloc(tlen);
+		if (kind == 0) rand_pair(qlen, tlen, err, q, t);
+		else { /* the query sits somewhere inside a longer random target, mutated */
+			int off = rng() % (tlen - qlen + 1);
+			for (j = 0; j < tlen; ++j) t[j] = rng() & 3;
+			rand_pair(qlen, qlen, err, q, t + off);
+			if ((rng() & 3) == 0) for (j = 0; j < qlen && off + qlen + 40 + j < tlen; ++j) t[off + qlen + 40 + j] = q[j]; /* a second copy */
+		}
+		push(&v, qlen); push(&v, tlen); push(&v, xtra); push(&v, g[0]); push(&v, g[1]); push(&v, g[2]); push(&v, g[3]);
+		for (j = 0; j < 25; ++j) push(&v, mat[j]);
+		for (j = 0; j < qlen; ++j) push(&v, q[j]);
+		for (j = 0; j < tlen; ++j) push(&v, t[j]);
+		r = ksw_align2(qlen, q, tlen, t, 5, mat, g[0], g[1], g[2], g[3], xtra, 0);
+		push(&v, r.score); push(&v, r.te); push(&v, r.qe); push(&v, r.score2); push(&v, r.te2); push(&v, r.tb); push(&v, r.qb);
+		rec_write(out, TAG_KSW_ALN2, v.n, v.a);
+		free(v.a); free(q); free(t);
+	}
+	fclose(out);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 2) {
@@ -348,6 +405,7 @@ int main(int argc, char **argv)
 	if (strcmp(argv[1], "stages") == 0) return main_stages(argc - 1, argv + 1);
 	if (strcmp(argv[1], "katfm") == 0) return main_katfm(argc - 1, argv + 1);
 	if (strcmp(argv[1], "katksw") == 0) return main_katksw(argc - 1, argv + 1);
+	if (strcmp(argv[1], "katalign") == 0) return main_katalign(argc - 1, argv + 1);
 	fprintf(stderr, "unknown sub-command '%s'\n", argv[1]);
 	return 1;
 }

@@ -10,6 +10,10 @@ the outputs below are data (inputs + expected outputs), never reference source.
   tests/golden/se.sam.gz, se_all.sam.gz, pe.sam.gz   SAM bodies from the reference's mem_process_seqs
   tests/golden/se.stages.npz       per-read stage dump (intervals, chains, filtered chains, regions)
   tests/golden/kat_fm.npz, kat_ksw.npz   known answers for Occ/SA/extend and ksw_extend2/global2/align2
+  tests/golden/kat_ksw_align.npz   ksw_align2 under other matrices / gap costs / xtra (word kernel as mem_seed_sw uses it)
+  tests/golden/opt_<set>.sam.gz    SAM bodies of se.fq / pe_[12].fq under non-default options (common.GOLDEN_OPTION_SETS)
+
+`make_golden.py extras` writes only the last two groups (round 2 additions); the older files are left alone.
 """
 import gzip
 import hashlib
@@ -97,5 +101,31 @@ def main():
     sh("ls", "-la", HERE)
 
 
+def extras():
+    """Round-2 additions, generated from the committed inputs (g60k.fa.gz, se.fq.gz, pe_[12].fq.gz)."""
+    assert os.path.exists("/root/reference/bwamem.c") and os.access(REF, os.X_OK), "needs the reference build (make -C oracle ref)"
+    os.makedirs(TMP, exist_ok=True)
+    for n in ("g60k.fa", "se.fq", "pe_1.fq", "pe_2.fq"):
+        open(f"{TMP}/{n}", "wb").write(gzip.open(f"{HERE}/{n}.gz").read())
+    sh("cp", f"{HERE}/g60k.alt", f"{TMP}/g60k.alt")
+    sh(REF, "index", f"{TMP}/g60k.fa", f"{TMP}/g60k")
+    sh(REF, "katalign", f"{TMP}/kat_ksw_align.bin", "400", "11")
+    records_to_npz(f"{TMP}/kat_ksw_align.bin", f"{HERE}/kat_ksw_align.npz")
+    # long reads (600-700 bases, 4 % substitutions, indels, chimeras): the seed SW filter drops seeds only there
+    parts = []
+    for k, ln in enumerate((600, 650, 700)):
+        bw.make_reads(f"{TMP}/g60k.fa", f"{TMP}/l{k}.fq", None, 25, ln, 40000, 3000, 500, 320 + k, 50000)
+        parts.append(open(f"{TMP}/l{k}.fq").read().replace("@r", f"@l{k}_"))
+    open(f"{TMP}/long.fq", "w").write("".join(parts))
+    gz(f"{TMP}/long.fq", f"{HERE}/long.fq.gz")
+    for name in common.GOLDEN_OPTION_SETS:
+        flags = common.option_flags(name)
+        fqs = [f"{TMP}/pe_1.fq", f"{TMP}/pe_2.fq"] if name in common.PE_OPTION_SETS else [f"{TMP}/long.fq"] if name in common.LONG_OPTION_SETS else [f"{TMP}/se.fq"]
+        with open(f"{TMP}/opt.sam", "wb") as f:
+            sh(REF, "mem", *flags, f"{TMP}/g60k", *fqs, stdout=f, stderr=subprocess.DEVNULL)
+        gz(f"{TMP}/opt.sam", f"{HERE}/opt_{name}.sam.gz")
+    sh("ls", "-la", HERE)
+
+
 if __name__ == "__main__":
-    main()
+    extras() if len(sys.argv) > 1 and sys.argv[1] == "extras" else main()

@@ -136,3 +136,37 @@ def test_ksw_known_answers():
             assert [r.score, r.te, r.qe, r.score2, r.te2, r.tb, r.qb] == res
         counts[tag] += 1
     assert all(c >= 100 for c in counts.values())
+
+
+def test_oracle_option_sweep_equals_reference_sam(gold):
+    """The restatement under non-default options vs SAM the reference produced with the same options (opt_*.sam.gz),
+    incl. -W on 600-700 base reads where mem_flt_chained_seeds (bwamem.c:605) really drops seeds."""
+    open(os.path.join(gold["dir"], "long.fq"), "wb").write(gzip.open(os.path.join(G, "long.fq.gz")).read())
+    for name in common.GOLDEN_OPTION_SETS:
+        fqs = ["pe_1.fq", "pe_2.fq"] if name in common.PE_OPTION_SETS else ["long.fq"] if name in common.LONG_OPTION_SETS else ["se.fq"]
+        want = gzip.open(os.path.join(G, f"opt_{name}.sam.gz")).read()
+        got = _run_oracle(["mem", "-t", "4"] + common.option_flags(name) + [gold["prefix"]] + [os.path.join(gold["dir"], f) for f in fqs])
+        assert got == want, name
+
+
+def test_oracle_ksw_align2_other_matrices(built):
+    """ora_ksw_align2 vs the reference's ksw_align2 under other matrices / gap costs / xtra (kat_ksw_align.npz)."""
+    ora = C.CDLL(os.path.join(common.ROOT, "oracle", "liboracle.so"))
+
+    class R(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+    ora.ora_ksw_align2.restype = R
+    ora.ora_ksw_align2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5
+    n = 0
+    for tag, v in bw.parse_records(np.load(os.path.join(G, "kat_ksw_align.npz"))["words"]):
+        if tag != 23:
+            continue
+        v = [int(x) for x in v]
+        qlen, tlen, xtra = v[0], v[1], v[2]
+        mat = np.array(v[7:32], dtype=np.int8)
+        q = np.array(v[32:32 + qlen], dtype=np.uint8)
+        t = np.array(v[32 + qlen:32 + qlen + tlen], dtype=np.uint8)
+        r = ora.ora_ksw_align2(qlen, q.ctypes.data, tlen, t.ctypes.data, 5, mat.ctypes.data, v[3], v[4], v[5], v[6], xtra)
+        assert [r.score, r.te, r.qe, r.score2, r.te2, r.tb, r.qb] == v[32 + qlen + tlen:], (n, v[:7])
+        n += 1
+    assert n >= 300

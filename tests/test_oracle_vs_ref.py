@@ -43,3 +43,36 @@ def test_mkindex_equals_reference_index(small_index, tmp_path):
     subprocess.check_call([common.BWAREF, "index", small_index["fa"], ref_prefix], stderr=subprocess.DEVNULL)
     for e in ("pac", "ann", "amb", "bwt", "sa"):
         assert open(ref_prefix + "." + e, "rb").read() == open(small_index["prefix"] + "." + e, "rb").read(), e
+
+
+@pytest.fixture(scope="module")
+def sweep_reads(small_index, tmp_path_factory):
+    d = tmp_path_factory.mktemp("sweep")
+    fq = str(d / "se.fq")
+    parts = []
+    for k, (n, ln, sub, indel, nn, chim) in enumerate([(700, 150, 15000, 3000, 500, 30000), (250, 250, 50000, 4000, 500, 30000), (100, 650, 40000, 3000, 500, 50000)]):
+        p = str(d / f"p{k}.fq")
+        bw.make_reads(small_index["fa"], p, None, n, ln, sub, indel, nn, 430 + k, chim)
+        parts.append(open(p).read().replace("@r", f"@s{k}_"))
+    open(fq, "w").write("".join(parts))
+    f1, f2 = str(d / "1.fq"), str(d / "2.fq")
+    bw.make_reads(small_index["fa"], f1, f2, 2000, 150, 20000, 2000, 500, 440)
+    return fq, f1, f2
+
+
+@pytest.mark.parametrize("name", sorted(common.OPTION_SETS) + sorted(common.LONG_OPTION_SETS))
+def test_option_sweep_se(small_index, sweep_reads, tmp_path, name):
+    """Oracle vs the reference under non-default options: SAM and every stage dump."""
+    flags = common.option_flags(name)
+    fq = sweep_reads[0]
+    assert _sam(common.ORACLE, flags + [small_index["prefix"], fq]) == _sam(common.BWAREF, flags + [small_index["prefix"], fq])
+    subprocess.check_call([common.ORACLE, "stages", *flags, small_index["prefix"], fq, str(tmp_path / "o.bin")])
+    subprocess.check_call([common.BWAREF, "stages", *flags, small_index["prefix"], fq, str(tmp_path / "r.bin")])
+    assert open(tmp_path / "o.bin", "rb").read() == open(tmp_path / "r.bin", "rb").read()
+
+
+@pytest.mark.parametrize("name", sorted(common.PE_OPTION_SETS))
+def test_option_sweep_pe(small_index, sweep_reads, name):
+    flags = common.option_flags(name)
+    _, f1, f2 = sweep_reads
+    assert _sam(common.ORACLE, flags + [small_index["prefix"], f1, f2]) == _sam(common.BWAREF, flags + [small_index["prefix"], f1, f2])
