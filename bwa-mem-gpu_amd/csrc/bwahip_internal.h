@@ -94,6 +94,7 @@ struct HostIndex {           // host copy of a loaded index (index_io.cpp)
 };
 int bwahip_load_index_files(const char *prefix, HostIndex *out);   // index_io.cpp
 void bwahip_free_host_index(HostIndex *h);
+int bwahip_copy_host_index(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, HostIndex *out);
 
 DevOpt make_dev_opt(const bwahip_opt_t *o);
 

@@ -33,7 +33,7 @@ struct Aln {                       // mem_aln_t, bwa.h:173-184
 	int n_cigar() const { return (int)cigar.size(); }
 };
 
-struct Ref { const bwahip_bns_t *bns; const uint8_t *pac; int64_t l_pac; };
+struct Ref { const bwahip_bns_t *bns; const uint8_t *pac; int64_t l_pac; const char *rg_id; };   // rg_id: bwa_rg_id (bwa.c:44), "" = none
 
 // ---------------------------------------------------------------- ksort.h:146-227
 template <class T, class LT> static void insertion(T *s, T *t, LT lt)
@@ -446,7 +446,6 @@ static void add_cigar(const Opt &o, const Aln &p, std::string &s, int which)
 	} else s.push_back('*');
 }
 struct Read { const char *name, *comment, *qual; const char *seq; int l_seq; };
-static const char *g_rg_id = "";
 
 static void aln2sam(const Opt &o, const Ref &r, std::string &str, const Read &s, int n, const Aln *list, int which, const Aln *m_)
 {
@@ -504,7 +503,7 @@ static void aln2sam(const Opt &o, const Ref &r, std::string &str, const Read &s,
 	if (m && m->n_cigar()) { str += "\tMC:Z:"; add_cigar(o, *m, str, which); }
 	if (p.score >= 0) { str += "\tAS:i:"; put_int(str, p.score); }
 	if (p.sub >= 0) { str += "\tXS:i:"; put_int(str, p.sub); }
-	if (g_rg_id[0]) { str += "\tRG:Z:"; str += g_rg_id; }
+	if (r.rg_id && r.rg_id[0]) { str += "\tRG:Z:"; str += r.rg_id; }
 	if (!(p.flag & 0x100)) {
 		int i;
 		for (i = 0; i < n; ++i) if (i != which && !(list[i].flag & 0x100)) break;
@@ -1044,7 +1043,7 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	par_for_chunks(n, opt->n_threads, [&](int64_t b, int64_t e) {
 		for (int64_t i = b; i < e; ++i) { regs[i].a.assign(regs_c[i].a, regs_c[i].a + regs_c[i].n); free(regs_c[i].a); }
 	});
-	hf::Ref ref = { bns, pac, bns->l_pac };
+	hf::Ref ref = { bns, pac, bns->l_pac, bwahip_ctx_rg_id(ctx) };
 	// phase 2 (serial): insert-size statistics (bwamem.c:1236-1239)
 	bwahip_pestat_t pes[4];
 	memset(pes, 0, sizeof pes);

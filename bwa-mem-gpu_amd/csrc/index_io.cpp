@@ -125,6 +125,32 @@ int bwahip_load_index_files(const char *prefix, HostIndex *out)
 	return 0;
 }
 
+// Deep copy of what finalisation needs on the host (contig table with names, holes, packed reference); the big FM-index
+// arrays are not copied (bwt.bwt / bwt.sa stay NULL in the copy).  pac == NULL: left to the caller to fill h->pac.
+int bwahip_copy_host_index(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, HostIndex *out)
+{
+	memset(out, 0, sizeof(*out));
+	out->owned = true;
+	out->bwt = *bwt; out->bwt.bwt = nullptr; out->bwt.sa = nullptr;
+	out->bns = *bns; out->bns.anns = nullptr; out->bns.ambs = nullptr; out->bns.fp_pac = nullptr;
+	out->bns.anns = (bwahip_ann_t*)calloc(bns->n_seqs > 0 ? bns->n_seqs : 1, sizeof(bwahip_ann_t));
+	if (!out->bns.anns) return BWAHIP_ENOMEM;
+	for (int i = 0; i < bns->n_seqs; ++i) {
+		out->bns.anns[i] = bns->anns[i];
+		out->bns.anns[i].name = strdup(bns->anns[i].name ? bns->anns[i].name : "");
+		out->bns.anns[i].anno = strdup(bns->anns[i].anno ? bns->anns[i].anno : "");
+	}
+	if (bns->n_holes > 0 && bns->ambs) {
+		out->bns.ambs = (bwahip_amb_t*)malloc((size_t)bns->n_holes * sizeof(bwahip_amb_t));
+		if (!out->bns.ambs) return BWAHIP_ENOMEM;
+		memcpy(out->bns.ambs, bns->ambs, (size_t)bns->n_holes * sizeof(bwahip_amb_t));
+	} else out->bns.n_holes = 0;
+	out->pac = (uint8_t*)malloc((size_t)bns->l_pac / 4 + 1);
+	if (!out->pac) return BWAHIP_ENOMEM;
+	if (pac) memcpy(out->pac, pac, (size_t)bns->l_pac / 4 + 1);
+	return 0;
+}
+
 void bwahip_free_host_index(HostIndex *h)
 {
 	if (!h || !h->owned) return;

@@ -124,11 +124,12 @@ struct Knobs {
 struct bwahip_ctx {
 	bool external_index = false;
 	Knobs knobs;
+	std::string rg_id;                   // read-group id appended as RG:Z: to every record (bwa_rg_id, bwa.c:44); empty = none
 	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
 	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
-	HostIndex host;                      // host copy (owned when loaded from files)
+	HostIndex host = {};                 // host copy: contig table + packed reference (always owned); FM-index arrays only when loaded from files
 	DevIndex ix;
 	DevBuf d_bwt, d_sa, d_pac, d_anns;
 	// batch state
@@ -259,10 +260,11 @@ int bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t 
 		return BWAHIP_ENODEV;
 	}
 	bwahip_ctx *c = new bwahip_ctx();
-	memset(&c->host, 0, sizeof c->host);
 	c->device = device;
-	c->host.bwt = *bwt; c->host.bns = *bns; c->host.pac = (uint8_t*)pac; c->host.owned = false;
-	int rc = ctx_setup(c, bwt, bns, pac);
+	// the context keeps its own copy of the contig table and the packed reference (finalisation reads them); the caller's
+	// arrays are not referenced after this returns
+	int rc = bwahip_copy_host_index(bwt, bns, pac, &c->host);
+	if (!rc) rc = ctx_setup(c, bwt, bns, pac);
 	if (rc) { bwahip_destroy(c); return rc; }
 	*out = c;
 	return 0;
@@ -277,11 +279,12 @@ int bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, con
 		return BWAHIP_ENODEV;
 	}
 	bwahip_ctx *c = new bwahip_ctx();
-	memset(&c->host, 0, sizeof c->host);
 	c->device = device; c->external_index = true;
-	c->host.bwt = *bwt_dev; c->host.bwt.bwt = nullptr; c->host.bwt.sa = nullptr;   // no host copy of the big arrays
-	c->host.bns = *bns; c->host.pac = nullptr; c->host.owned = false;
-	int rc = ctx_setup(c, bwt_dev, bns, pac_dev);
+	// host copy of the contig table, and of the packed reference read back from the adopted device array (l_pac/4+1 bytes),
+	// so that a rank that received its index over RCCL can run bwahip_process_seqs like the rank that loaded it
+	int rc = bwahip_copy_host_index(bwt_dev, bns, nullptr, &c->host);
+	if (!rc) rc = ctx_setup(c, bwt_dev, bns, pac_dev);
+	if (!rc && hipMemcpy(c->host.pac, pac_dev, (size_t)bns->l_pac / 4 + 1, hipMemcpyDeviceToHost) != hipSuccess) rc = BWAHIP_ENODEV;
 	if (rc) { bwahip_destroy(c); return rc; }
 	*out = c;
 	return 0;
@@ -327,6 +330,8 @@ void bwahip_destroy(bwahip_ctx *c)
 	delete c;
 }
 
+int bwahip_ctx_set_rg_id(bwahip_ctx *c, const char *id) { if (!c) return BWAHIP_EINVAL; c->rg_id = id ? id : ""; return 0; }
+const char *bwahip_ctx_rg_id(const bwahip_ctx *c) { return c ? c->rg_id.c_str() : ""; }
 const bwahip_bns_t *bwahip_bns(const bwahip_ctx *c) { return c ? &c->host.bns : nullptr; }
 const bwahip_bwt_t *bwahip_bwt(const bwahip_ctx *c) { return c ? &c->host.bwt : nullptr; }
 const uint8_t *bwahip_pac(const bwahip_ctx *c) { return c ? c->host.pac : nullptr; }

@@ -161,10 +161,12 @@ typedef struct bwahip_ctx bwahip_ctx;
 /* ---- lifetime ------------------------------------------------------------
  * bwahip_init replaces newProcess()/transferIndex() (cuda/streams.cu:8,164): it copies the three
  * index arrays (bwt, sa, pac) and the contig table into HBM of HIP device `device` and builds the
- * launch workspaces.  The host arrays are not referenced after it returns. */
+ * launch workspaces.  The context keeps its own host copy of the contig table (names included) and of the
+ * packed reference; the caller's arrays are not referenced after it returns. */
 int  bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, int device, bwahip_ctx **out);
 /* Same, but bwt_dev->bwt, bwt_dev->sa and pac_dev already point into HBM of `device` (e.g. filled by an RCCL
- * broadcast from the rank that loaded the index); the arrays stay owned by the caller and must outlive the ctx. */
+ * broadcast from the rank that loaded the index); the device arrays stay owned by the caller and must outlive the
+ * ctx.  bns is a host struct; the packed reference is read back once (l_pac/4+1 bytes) for host-side finalisation. */
 int  bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out);
 /* Convenience: read a stock `bwa index` file set <prefix>.{bwt,sa,pac,ann,amb[,alt]} (bwa.c:402 bwa_idx_load) and init. */
 int  bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out);
@@ -174,6 +176,10 @@ void bwahip_destroy(bwahip_ctx *ctx);
 const bwahip_bns_t *bwahip_bns(const bwahip_ctx *ctx);
 const bwahip_bwt_t *bwahip_bwt(const bwahip_ctx *ctx);
 const uint8_t      *bwahip_pac(const bwahip_ctx *ctx);
+/* Read-group id printed as RG:Z:<id> on every record (the reference's global bwa_rg_id, bwa.c:44, set by -R); NULL or
+ * "" = none. */
+int bwahip_ctx_set_rg_id(bwahip_ctx *ctx, const char *id);
+const char *bwahip_ctx_rg_id(const bwahip_ctx *ctx);
 void bwahip_opt_init(bwahip_opt_t *opt);     /* mem_opt_init defaults, bwamem.c:74 */
 void bwahip_opt_fill_scmat(bwahip_opt_t *opt);   /* bwa_fill_scmat(opt->a, opt->b, opt->mat), bwa.c:249: call after changing a or b */
 

@@ -21,6 +21,33 @@ def test_library_exports_every_declared_symbol(built):
     assert not missing, f"declared in bwahip.h but not exported: {missing}"
 
 
+def test_compat_library_exports_mem_process_seqs(built):
+    """libbwamem_hip.so exports the symbol the north star names, mem_process_seqs (bwamem.h:69), and the two helpers
+    include/bwamem_hip.h declares; it resolves against libbwahip.so."""
+    lib = C.CDLL(os.path.join(os.path.dirname(bw.LIB_PATH), "libbwamem_hip.so"))
+    for sym in ("mem_process_seqs", "bwahip_compat_set_rg_id", "bwahip_compat_release"):
+        assert hasattr(lib, sym), sym
+    assert os.access(os.path.join(common.ROOT, "tests", "c_abi_driver"), os.X_OK), "plain-C driver was not built"
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/bwamem.h"), reason="reference headers not present")
+def test_reference_translation_unit_links_against_compat_library(built, tmp_path):
+    """A C file that includes only the REFERENCE's bwamem.h and calls mem_process_seqs through the reference's prototype
+    compiles and links against libbwamem_hip.so with no bwamem.o in sight (never run here: no GPU)."""
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include "bwamem.h"
+int main(int argc, char **argv) {
+    mem_opt_t *opt = 0; bwt_t *bwt = 0; bntseq_t *bns = 0; uint8_t *pac = 0; bseq1_t *seqs = 0;
+    if (argc > 100) mem_process_seqs(opt, bwt, bns, pac, 0, 0, seqs, 0);   /* bwamem.h:69 */
+    return 0; }''')
+    exe = tmp_path / "caller"
+    pkg = os.path.dirname(bw.LIB_PATH)
+    subprocess.check_call(["gcc", "-I/root/reference", str(src), "-o", str(exe), "-L" + pkg, "-lbwamem_hip", "-lbwahip", "-Wl,-rpath," + pkg])
+    r = subprocess.run(["nm", "-D", "--undefined-only", str(exe)], stdout=subprocess.PIPE, text=True)
+    assert "mem_process_seqs" in r.stdout
+
+
 def test_struct_sizes_match_reference_layouts(built):
     assert C.sizeof(bw.Opt) == 168 and bw.Opt.mat.offset == 136          # mem_opt_t (bwa.h:86-118)
     assert C.sizeof(bw.AlnReg) == 88                                        # mem_alnreg_t (bwa.h:145-163)
