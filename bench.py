@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/s of the MI355X BWA-MEM hot path (mem_align1_core on the GPU: SMEM collection, SA
-look-up, chaining + filter, banded-SW extension, dedup/patch), with the roofline of the BWT-search kernel
-and a CPU baseline timed on this node's cores in the same run.
+"""bench.py -- reads/s of the MI355X BWA-MEM hot path on BASELINE.json's headline configuration: 150 bp paired-end
+reads (2x150, insert N(500,50^2), FR) against an hg38-scale genome (3.1 Gbp; GRCh38 itself is not available offline, so a
+deterministic synthetic genome with repeat families is used and named as such), with the roofline of the BWT-search
+kernel, the end-to-end rate (host buffers in -> SAM text out), a byte-for-byte check of that SAM against the reference's
+own CPU path on the same reads, and the CPU path timed on this node's cores in the same run.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one pass of the whole hot path over one resident batch (codes in HBM -> alignment regions in
-HBM).  Reads are sharded per rank with no data-path collective ("weak" scaling: every rank aligns its own
-batch); RCCL is used once, to broadcast the index from rank 0.
+A "step" = one pass of the whole GPU pipeline over this rank's resident read set (default 10 M reads = 5 M pairs, BASELINE
+configs[2]), processed in batches of 1 M reads exactly as `bwa mem -K 150000000` would cut them; inputs (base codes) are
+in HBM when the timed region starts, results stay in HBM.  Reads are sharded per rank with no data-path collective
+("weak" scaling: every rank aligns its own reads); RCCL is used once, to broadcast the index from rank 0.
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import re
@@ -30,21 +34,35 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def usable_cpus():
+    """CPUs this process can really use: affinity mask and the container's CFS quota (cgroup v2 cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BWAHIP_BENCH_MBP", "512")),
-                    help="size of the synthetic genome (GRCh38 itself is not available offline)")
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("BWAHIP_BENCH_READS", "1000000")))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BWAHIP_BENCH_MBP", "3100")),
+                    help="size of the synthetic genome (GRCh38 itself is not available offline); hg38 is 3.1 Gbp")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BWAHIP_BENCH_READS", "10000000")),
+                    help="reads per GPU and step (PE: mates interleaved, so half as many pairs)")
+    ap.add_argument("--batch", type=int, default=1000000, help="reads per mem_process_seqs batch (bwa mem -K 150000000 at 150 bp)")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--se", action="store_true", help="single-end reads (BASELINE configs[1]) instead of paired-end")
     ap.add_argument("--sub-ppm", type=int, default=10000, help="substitution errors per million bases (configs[4]: 50000)")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BWAHIP_BENCH_CPU_READS", "200000")))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BWAHIP_BENCH_CPU_READS", "1000000")),
+                    help="reads of the same workload given to the CPU path (and compared byte for byte with the GPU path's SAM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="exploratory: split the batch into this many sub-batches, each with its own context and stream, run "
-                         "concurrently (stages of different sub-batches overlap; per-kernel timings then overlap too)")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -52,6 +70,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    pe = not args.se
+    if pe:
+        args.reads &= ~1
+        args.batch &= ~1
+    args.batch = min(args.batch, args.reads)
     import torch
     dist = None
     if world > 1:
@@ -66,6 +89,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
 
     import __graft_entry__ as entry
     bw = entry.load_bwahip()
@@ -78,15 +102,18 @@ def main():
     fa = prefix + ".fa"
     t_index = 0.0
     lens = tp.contig_lengths(args.genome_mbp * 1000000)
-    # ---------------- index: rank 0 builds (stock bwa format), the others receive it over RCCL
+    cpus = usable_cpus()
+    # ---------------- genome + index: rank 0 builds (stock bwa format, cached under /dev/shm), the others receive it over RCCL
+    genome = None
     if rank == 0:
         t0 = time.time()
-        genome = tp.make_genome(38, lens, repeats=True)
-        if not os.path.exists(prefix + ".sa"):
+        if not (os.path.exists(prefix + ".sa") and os.path.exists(fa)):
+            genome = tp.make_genome(38, lens, repeats=True)
             tp.write_fasta(fa, genome, lens)
+            log(f"genome {args.genome_mbp} Mbp generated and written: {time.time() - t0:.1f}s")
             bw.make_index(fa, prefix)
         t_index = time.time() - t0
-        log(f"genome {args.genome_mbp} Mbp + index: {t_index:.1f}s")
+        log(f"genome + index ready: {t_index:.1f}s")
     if world > 1:
         dist.barrier()
     t0 = time.time()
@@ -98,44 +125,39 @@ def main():
         if rank != 0:
             ctx, holder = ctx_or_holder
     t_bcast = time.time() - t0
+    log(f"rank {rank}: index resident in HBM ({t_bcast:.1f}s)")
 
-    # ---------------- reads: every rank its own batch (seed 102 + rank), 1 % substitutions, 50 % reverse strand
-    if rank != 0:
-        genome = tp.make_genome(38, lens, repeats=True)
-    reads = tp.make_reads(genome, lens, args.reads, args.read_len, sub_ppm=args.sub_ppm, seed=102 + rank)
-    codes = bw.NT4[reads.reshape(-1)]
-    off = np.arange(args.reads + 1, dtype=np.int64) * args.read_len
-    log(f"rank {rank}: {args.reads} reads generated")
+    # ---------------- reads: every rank its own set (seed 103 + rank), 1 % substitutions, 50 % reverse strand; PE: FR pairs,
+    # insert N(500, 50^2) clipped to [300, 700], mates interleaved.  The genome bytes come from the FASTA rank 0 wrote.
+    if genome is None:
+        genome = tp.read_fasta_bases(fa, lens)
+    t0 = time.time()
+    reads = tp.make_reads(genome, lens, args.reads, args.read_len, sub_ppm=args.sub_ppm, seed=(103 if pe else 102) + rank, paired=pe)
+    log(f"rank {rank}: {args.reads} reads generated ({time.time() - t0:.1f}s)")
+    rl = args.read_len
+    n_batches = (args.reads + args.batch - 1) // args.batch
+    codes_dev = torch.empty(args.reads * rl, dtype=torch.uint8, device=dev)
+    for b0 in range(0, args.reads, 2000000):                   # staged: the ASCII -> code table look-up doubles the host footprint otherwise
+        b1 = min(args.reads, b0 + 2000000)
+        codes_dev[b0 * rl:b1 * rl] = torch.from_numpy(bw.NT4[reads[b0:b1].reshape(-1)]).to(dev)
+    off_dev = torch.arange(args.batch + 1, dtype=torch.int64, device=dev) * rl
+    torch.cuda.synchronize()
     opt = bw.default_opt()
-    lanes = None
-    if args.lanes > 1:
-        # sub-batches: contexts that adopt one shared copy of the index (bwahip_init_device), one host thread each
-        from concurrent.futures import ThreadPoolExecutor
-        meta, arrays = tp.load_index_arrays(prefix)
-        shared = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in arrays.items()}
-        torch.cuda.synchronize()
-        lanes = [bw.Context.from_device_arrays(meta, shared["bwt"].data_ptr(), shared["sa"].data_ptr(), shared["pac"].data_ptr(), local_rank)
-                 for _ in range(args.lanes)]
-        per = (args.reads + args.lanes - 1) // args.lanes
-        for i, lc in enumerate(lanes):
-            b0, b1 = i * per, min(args.reads, (i + 1) * per)
-            lc.batch_upload(codes[b0 * args.read_len:b1 * args.read_len], off[b0:b1 + 1] - off[b0])
-        pool = ThreadPoolExecutor(args.lanes)
+    if pe:
+        opt.flag |= 0x2
+    opt.n_threads = max(1, cpus // world)
 
-        class Lanes:                                    # same surface as one context for the loop below
-            def batch_run(self, o):
-                return list(pool.map(lambda lc: lc.batch_run(o), lanes))[0]
+    def batch_bounds(b):
+        b0 = b * args.batch
+        return b0, min(args.reads, b0 + args.batch)
 
-            def counters(self):
-                tot = None
-                for lc in lanes:
-                    cs = lc.counters()
-                    tot = cs if tot is None else {k: (max(tot[k], v) if k.endswith("_max") or k.startswith("max_") else tot[k] + v) for k, v in cs.items()}
-                return tot
-        ctx = Lanes()
-    else:
-        ctx.batch_upload(codes, off)
-    log("batch uploaded")
+    def run_step(collect=None):
+        for b in range(n_batches):
+            b0, b1 = batch_bounds(b)
+            ctx.batch_attach(b1 - b0, codes_dev.data_ptr() + b0 * rl, off_dev.data_ptr(), rl, (b1 - b0) * rl)
+            km = ctx.batch_run(opt)
+            if collect is not None:
+                collect.append(km)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -144,45 +166,70 @@ def main():
             torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        km = ctx.batch_run(opt)
-        log(f"warmup {w}: kernel ms {km}")
+        kms = []
+        run_step(kms)
+        log(f"warmup {w}: kernel ms of batch 0 {dict((k, round(v, 2)) for k, v in kms[0].items())}")
     sync_all()
     t0 = time.time()
     kms = []
     for _ in range(args.steps):
-        kms.append(ctx.batch_run(opt))
+        run_step(kms)
     sync_all()
     elapsed = time.time() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    counters = ctx.counters()
+    # algorithmic work per launch, counted by the kernels themselves: one more (untimed) pass, counters read after every batch
+    cnts = []
+    for b in range(n_batches):
+        b0, b1 = batch_bounds(b)
+        ctx.batch_attach(b1 - b0, codes_dev.data_ptr() + b0 * rl, off_dev.data_ptr(), rl, (b1 - b0) * rl)
+        ctx.batch_run(opt)
+        cnts.append(ctx.counters())
+    counters = {k: (max(c[k] for c in cnts) if k.endswith("_max") or k.startswith("max_") else sum(c[k] for c in cnts)) for k in cnts[0]}
+
+    # ---------------- end to end (host buffers in -> SAM text out) on the first --cpu-sample reads, one mem_process_seqs batch
+    n_s = min(args.cpu_sample, args.reads) & (~1 if pe else ~0)
+    e2e = None
+    sam_gpu = None
+    if not args.no_e2e:
+        names = tp.fixed_names(n_s, pe)
+        t_e2e, sam_gpu = tp.process_seqs_bulk(bw, ctx, opt, names, reads[:n_s])
+        if world > 1:
+            tm = torch.tensor([t_e2e], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            t_e2e = float(tm.item())
+        e2e = {"reads_per_s": n_s * world / t_e2e, "seconds": t_e2e, "reads": n_s * world, "host_threads_per_gpu": opt.n_threads}
+        log(f"e2e: {n_s} reads through bwahip_process_seqs in {t_e2e:.3f}s with {opt.n_threads} host threads")
 
     if rank == 0:
+        n_launch = len(kms)
         ms_step = elapsed / args.steps * 1e3
         value = args.reads * world * args.steps / elapsed
         k1 = float(np.mean([k["k_smem"] for k in kms]))
-        # algorithmic bytes of the BWT-search kernel per launch: 64 B per Occ block touched by
-        # bwt_extend + the read bytes in + 32 B per interval out, counted by the kernel itself
-        # (the few reads k_smem hands to k_smem_heavy are counted by that kernel and subtracted here)
-        # (pass 3 runs in k_smem3; its blocks and intervals are counted by that kernel and subtracted too)
-        alg_bytes = (64 * (counters["blocks"] - counters["heavy_blocks"] - counters["pass3_blocks"]) + args.reads * args.read_len +
+        # algorithmic bytes of the BWT-search kernel per launch: 64 B per Occ block touched by bwt_extend +
+        # the read bytes in + 32 B per interval out, counted by the kernel itself (the few reads k_smem hands to
+        # k_smem_heavy, and pass 3 which runs in k_smem3, are counted by those kernels and subtracted)
+        alg_total = (64 * (counters["blocks"] - counters["heavy_blocks"] - counters["pass3_blocks"]) + args.reads * rl +
                      32 * (counters["intv"] - counters["heavy_intv"] - counters["pass3_intv"]))
+        alg_bytes = alg_total / n_batches
         achieved = alg_bytes / (k1 * 1e-3) / 1e9
+        kind = (f"{args.reads // 2} pairs (2x{rl} bp, FR, insert N(500,50^2) clipped [300,700])" if pe else f"{args.reads} SE reads of {rl} bp")
         out = {
-            "metric": "reads/s aligned (150 bp vs hg38-scale synthetic genome), hot path mem_align1_core on GPU",
+            "metric": f"reads/s aligned ({rl} bp {'PE' if pe else 'SE'} vs hg38-scale {args.genome_mbp} Mbp synthetic genome), GPU pipeline with reads resident in HBM",
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.reads} synthetic {args.read_len} bp SE reads ({args.sub_ppm / 10000:g}% substitutions) per GPU vs "
+            "config": {"workload": f"{kind}, {args.sub_ppm / 10000:g}% substitutions, per GPU and step, in batches of {args.batch} reads (-K {args.batch * rl}) vs "
                                    f"{args.genome_mbp} Mbp synthetic genome with repeat families (GRCh38 not available offline); "
-                                   "BASELINE configs[1] shape",
-                       "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp, "lanes": args.lanes,
-                       "stages": ["k_smem(passes 1-2)+k_smem_heavy+k_smem3(pass 3)+k_intv_sort", "k_seeds", "k_chain", "k_extend_spec+k_extend(+dedup/patch)"],
-                       "output": "mem_alnreg_v per read resident in HBM (== mem_align1_core)",
-                       "index_build_s": round(t_index, 1), "index_broadcast_s": round(t_bcast, 2)},
+                                   f"BASELINE configs[{2 if pe else 1}] shape",
+                       "reads_per_gpu": args.reads, "batch_reads": args.batch, "read_len": rl, "paired": pe, "genome_mbp": args.genome_mbp,
+                       "stages": ctx.stage_names(),
+                       "output": ctx.output_description(pe),
+                       "index_build_s": round(t_index, 1), "index_to_hbm_s": round(t_bcast, 2), "host_cpus_usable": cpus},
             "kernel_ms": {k: round(float(np.mean([x[k] for x in kms])), 3) for k in kms[0]},
+            "launches_timed": n_launch,
             "per_read": {"bwt_extend": round(counters["extend"] / args.reads, 1), "occ_blocks": round(counters["blocks"] / args.reads, 1),
                          "sa_lookups": round(counters["sa"] / args.reads, 2), "lf_steps": round(counters["lf"] / args.reads, 1),
                          "dp_cells": round(counters["cells"] / args.reads, 1),
@@ -191,13 +238,17 @@ def main():
             "tail_counts": {"max_extends_per_read": counters.get("max_extends"), "max_seeds_per_read": counters.get("max_seeds"), "max_chains_per_read": counters.get("max_chains")},
             "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k1, 3)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k1, 3), "reads_per_launch": args.batch},
         }
-        # HBM traffic of the same kernel from the committed PMC pass of this very command (counters cannot be read from inside
-        # the process); only quoted when the workload string matches
+        if e2e:
+            out["value_e2e"] = round(e2e["reads_per_s"], 1)
+            out["e2e"] = {"what": "bwahip_process_seqs: host bseq1_t arrays in (ASCII reads, names, qualities) -> seqs[i].sam text out, one batch per GPU, PCIe and host work included",
+                          "reads": e2e["reads"], "seconds": round(e2e["seconds"], 4), "host_threads_per_gpu": e2e["host_threads_per_gpu"]}
+        # HBM traffic of the same kernel from the committed PMC passes of this very command (counters cannot be read from
+        # inside the process); quoted only when workload AND kernel sources are the ones the counters were collected on
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == out["config"]["workload"]:
+            if pt.get("workload") == out["config"]["workload"] and pt.get("kernel_src_sha256") == kernel_src_sha():
                 out["roofline"]["traffic"] = int(pt["fetch_bytes_per_launch"] + pt["write_bytes_per_launch"])
                 out["roofline"]["traffic_source"] = pt["source"]
         except (OSError, ValueError, KeyError):
@@ -209,12 +260,45 @@ def main():
             out["roofline"]["measured_gather64_GBps"] = ceil["gather64_GBps"]
             out["roofline"]["measured_stream_copy_GBps"] = ceil["stream_copy_GBps"]
             out["roofline"]["frac_of_measured_gather"] = round(achieved / ceil["gather64_GBps"], 4)
+        parity_ok = None
         if not args.no_cpu_baseline and world == 1:               # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(tp, bw, prefix, genome, lens, args, workdir)
+            out["cpu_baseline"], sam_cpu_path = cpu_baseline(tp, prefix, reads[:n_s], pe, cpus, workdir)
+            if sam_gpu is not None and sam_cpu_path:
+                # the CPU SAM and the GPU SAM of the same reads in the same run must be byte-identical
+                parity_ok = file_equals(sam_cpu_path, sam_gpu)
+                out["parity_in_run"] = parity_ok
+                out["parity_checked"] = f"{n_s} reads: SAM of bwahip_process_seqs vs SAM of oracle/_ref/bwaref (the reference's own mem_process_seqs), byte for byte"
+                if not parity_ok:
+                    log("PARITY FAILURE: GPU SAM differs from the reference CPU path's SAM on the bench workload")
         print(json.dumps(out), flush=True)
+        if parity_ok is False:
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_src_sha():
+    h = hashlib.sha256()
+    for f in ("k_smem.hip", "fmi_dev.h"):
+        h.update(open(os.path.join(ROOT, "bwa-mem-gpu_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def file_equals(path, blob):
+    if os.path.getsize(path) != len(blob):
+        return False
+    with open(path, "rb") as f:
+        pos = 0
+        while True:
+            chunk = f.read(1 << 24)
+            if not chunk:
+                return True
+            if chunk != blob[pos:pos + len(chunk)]:
+                return False
+            pos += len(chunk)
 
 
 def measured_ceilings():
@@ -230,28 +314,43 @@ def measured_ceilings():
         return None
 
 
-def cpu_baseline(tp, bw, prefix, genome, lens, args, workdir):
-    """Time the CPU path on this node's cores on a bounded sample of the same workload: the reference's own
-    sources (oracle/_ref/bwaref, kind "reference") when the prebuilt binary is present, else our C restatement
-    (oracle/bwa_oracle, kind "port").  Reported beside the GPU number; not a target."""
-    n = min(args.cpu_sample, args.reads)
-    cores = os.cpu_count() or 1
-    fq = os.path.join(workdir, "cpu_sample.fq")
-    reads = tp.make_reads(genome, lens, n, args.read_len, sub_ppm=args.sub_ppm, seed=102)
-    tp.write_fastq(fq, reads)
+def cpu_baseline(tp, prefix, sample, pe, cpus, workdir):
+    """Time the CPU path on this node's cores on a bounded sample of the same workload: the reference's own sources
+    (oracle/_ref/bwaref, kind "reference") when the prebuilt binary is present, else our C restatement (oracle/bwa_oracle,
+    kind "port").  Two runs: mem_process_seqs (align + finalisation + SAM text; its SAM is kept for the parity check) and
+    the hot path alone (kt_for(worker1) == mem_align1_core per read, `-Z`), which is what the GPU `value` covers.
+    Reported beside the GPU number; not a target."""
+    n = len(sample)
+    fqs = tp.write_fastq_fixed(os.path.join(workdir, "cpu_sample"), sample, pe)
     ref = os.path.join(ROOT, "oracle", "_ref", "bwaref")
     port = os.path.join(ROOT, "oracle", "bwa_oracle")
     exe, kind = (ref, "reference") if os.access(ref, os.X_OK) else (port, "port")
-    # -K fixes the batch at 150 M bases (BASELINE.md section 3); without it the reference's own
-    # chunk_size * n_threads (fastmap.c:304) overflows int at this core count and degenerates to 1-read batches
-    log(f"cpu baseline: {os.path.basename(exe)} on {n} reads with {cores} threads ...")
-    r = subprocess.run([exe, "mem", "-t", str(cores), "-K", "150000000", prefix, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-    m = re.search(r"aligned (\d+) reads in ([0-9.]+) s", r.stderr)
-    if not m:
-        return {"value": None, "unit": "reads/s", "cores": cores, "kind": kind, "sample": f"failed: {r.stderr[-200:]}"}
-    secs = float(m.group(2))
-    return {"value": round(n / secs, 1), "unit": "reads/s", "cores": cores, "kind": kind,
-            "sample": f"{n} reads of the same workload through mem_process_seqs (align + SAM text) in {secs:.2f}s; index load excluded"}
+    sam_path = os.path.join(workdir, "cpu_sample.sam")
+    res = {"value": None, "unit": "reads/s", "cores": cpus, "kind": kind}
+
+    def run(extra, stdout):
+        # -K fixes the batch at 150 M bases (BASELINE.md section 3); without it the reference's own chunk_size * n_threads
+        # (fastmap.c:304) can overflow int and degenerate to 1-read batches
+        r = subprocess.run([exe, "mem", "-t", str(cpus), "-K", "150000000", *extra, prefix, *fqs], stdout=stdout, stderr=subprocess.PIPE, text=False)
+        m = re.search(rb"aligned (\d+) reads in ([0-9.]+) s", r.stderr)
+        return float(m.group(2)) if m and r.returncode == 0 else None, r.stderr[-300:]
+
+    log(f"cpu baseline: {os.path.basename(exe)} on {n} reads with {cpus} threads (mem_process_seqs, SAM kept for the parity check) ...")
+    with open(sam_path, "wb") as f:
+        secs, err = run([], f)
+    if secs is None:
+        res["sample"] = f"failed: {err!r}"
+        return res, None
+    res["value"] = round(n / secs, 1)
+    res["sample"] = (f"{n} reads of the same workload ({'PE' if pe else 'SE'}) as one batch through mem_process_seqs (align + finalisation + SAM text) "
+                     f"in {secs:.2f}s on {cpus} threads; index load excluded")
+    if kind == "reference":
+        log("cpu baseline: hot path only (kt_for(worker1)) ...")
+        secs2, _ = run(["-Z"], subprocess.DEVNULL)
+        if secs2:
+            res["hot_path_value"] = round(n / secs2, 1)
+            res["hot_path_sample"] = f"the same reads through kt_for(worker1) only (mem_align1_core per read, bwamem.c:1232) in {secs2:.2f}s: like-for-like with `value`"
+    return res, sam_path
 
 
 if __name__ == "__main__":

@@ -99,6 +99,7 @@ def lib():
     L.bwahip_destroy.argtypes = [vp]
     L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
     L.bwahip_batch_upload.argtypes = [vp, C.c_int, vp, vp]
+    L.bwahip_batch_attach.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int64]
     L.bwahip_batch_run.argtypes = [vp, C.POINTER(Opt), C.POINTER(C.c_float), C.c_int]
     L.bwahip_batch_counters.argtypes = [vp, u64p, C.c_int]
     L.bwahip_kernel_name.restype = C.c_char_p
@@ -109,6 +110,7 @@ def lib():
     L.bwahip_align_batch.argtypes = [vp, C.POINTER(Opt), C.c_int, C.POINTER(Seq), C.POINTER(AlnRegV)]
     L.bwahip_process_seqs.argtypes = [vp, C.POINTER(Opt), C.c_int64, C.c_int, C.POINTER(Seq), C.POINTER(PeStat)]
     L.bwahip_batch_download.argtypes = [vp, C.POINTER(AlnRegV)]
+    L.bwahip_seqs_take_sam.argtypes = [C.POINTER(Seq), C.c_int, C.POINTER(vp), i64p]
     _lib = L
     return L
 
@@ -241,12 +243,25 @@ class Context:
         off = np.ascontiguousarray(off, dtype=np.int64)
         _check(lib().bwahip_batch_upload(self._h, len(off) - 1, codes.ctypes.data, off.ctypes.data), "bwahip_batch_upload")
 
+    def batch_attach(self, n, seq_ptr, off_ptr, max_len, total_bases):
+        """Use reads already resident in HBM (device pointers); nothing is copied."""
+        _check(lib().bwahip_batch_attach(self._h, n, seq_ptr, off_ptr, max_len, total_bases), "bwahip_batch_attach")
+
     def batch_run(self, opt=None):
         opt = opt or default_opt()
         nk = lib().bwahip_n_kernels()
         ms = (C.c_float * nk)()
         _check(lib().bwahip_batch_run(self._h, C.byref(opt), ms, nk), "bwahip_batch_run")
         return {lib().bwahip_kernel_name(i).decode(): float(ms[i]) for i in range(nk)}
+
+    @staticmethod
+    def stage_names():
+        return ["k_smem(passes 1-2)+k_smem_heavy+k_smem3(pass 3)+k_intv_sort", "k_seeds", "k_chain(+k_chain_big,k_chain_flt)", "k_seed_sw (only with -W / reads > 700 bp)",
+                "k_extend_spec+k_extend(+k_extend_big, dedup/patch)"]
+
+    @staticmethod
+    def output_description(paired):
+        return "mem_alnreg_v per read resident in HBM (== mem_align1_core for every read" + (" of every pair)" if paired else ")")
 
     def counters(self):
         buf = (C.c_uint64 * 32)()

@@ -34,6 +34,9 @@ struct DevOpt {
 	int min_chain_weight, max_chain_extend;
 	float mask_level, drop_ratio, mask_level_redun;
 	int8_t mat[25];
+	// finalisation (mem_mark_primary_se .. mem_aln2sam) and pairing
+	int T, flag, pen_unpaired, max_ins, max_matesw, max_XA_hits, max_XA_hits_alt, mapQ_coef_fac;
+	float XA_drop_ratio, mapQ_coef_len;
 };
 
 // Work counters kept in HBM, bumped once per wavefront at kernel exit (bwahip_batch_counters).
@@ -177,6 +180,53 @@ struct ExtLaunch {
 constexpr int BWAHIP_EXT_BIG_GRID = 128, BWAHIP_EXT_BIG_T = 1 << 16;
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
 int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st);
+
+// ---- finalisation on the GPU (k_final.hip): mark primary -> alignments (CIGAR, NM, MD, mapQ) -> SAM text ----
+// Region with the fields finalisation adds (mem_alnreg_t, bwa.h:145-163, no bit-fields)
+struct FinReg {
+	int64_t rb, re; uint64_t hash; float frac_rep;
+	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
+	int32_t pad;
+};
+// mem_aln_t (bwa.h:173-184); its CIGAR words and MD text live in the batch's text pool
+struct DevAln {
+	int64_t pos; int32_t rid, flag; uint32_t is_rev, is_alt, mapq, NM;
+	int32_t n_cigar, score, sub, alt_sc;
+	int64_t cigar_off;                           // byte offset of n_cigar uint32 words in the pool
+	int64_t md_off; int32_t md_len, pad;
+};
+// what a region is needed for (FinLaunch::need)
+enum { NEED_REC = 1 /* prints a SAM record */, NEED_XA = 2 /* listed in another record's XA tag */ };
+
+struct FinLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const uint8_t *seq; const int64_t *off;
+	int64_t n_processed;
+	const double *logtab;
+	// regions of mem_align1_core (k_extend): regs[reg_base[r] .. +reg_n[r])
+	const DevReg *regs; const int64_t *reg_base; const int *reg_n;
+	// mark primary: fregs at the same slots, in the reference's final order; n_pri per read; scratch
+	FinReg *fregs, *fregs2; int *freg_n, *n_pri; int *scr;     // scr: 4 ints per region slot
+	uint8_t *need; int *xa_owner;                // per region slot
+	int *task_n, *rec_n;                         // per read: regions needing reg2aln; SAM records
+	// alignment tasks
+	const int64_t *task_base;                    // exclusive scan of task_n
+	int2 *tasks;                                 // (read, region index)
+	int *aln_of_reg;                             // per region slot: task id or -1
+	DevAln *alns;
+	uint8_t *pool; unsigned long long *pool_head; unsigned long long pool_cap;   // CIGAR / MD text: bump allocation
+	int *redo_list, *redo_n; uint8_t *big_z;     // tasks whose backtrack matrix / window exceed LDS (k_cigar_big)
+	// SAM text
+	const uint8_t *qual; const uint8_t *names; const int64_t *name_off; const uint8_t *comments; const int64_t *comment_off;   // per read (comments may be null)
+	const uint8_t *ctg_names; const int *ctg_name_off; const uint8_t *ctg_anno; const int *ctg_anno_off;
+	const uint8_t *rg_id; int rg_len;
+	int64_t *sam_len; const int64_t *sam_off; uint8_t *sam;    // per read length (pass 1), exclusive scan, text (pass 2)
+	int *err;
+};
+int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st);
+int launch_task_fill(const FinLaunch &a, hipStream_t st);
+int launch_cigar(const FinLaunch &a, int64_t n_tasks, hipStream_t st);
+int launch_sam(const FinLaunch &a, bool write, hipStream_t st);
 
 // K3b: mem_flt_chained_seeds on the chains k_chain / k_chain_flt left (k_seedsw.hip)
 struct SeedSwLaunch {

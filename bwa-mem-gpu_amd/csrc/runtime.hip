@@ -8,18 +8,19 @@
 
 // ------------------------------------------------------------------ small device helpers
 struct DevBuf {
-	void *p = nullptr; size_t cap = 0;
+	void *p = nullptr; size_t cap = 0; bool ext = false;   // ext: caller-owned device memory (bwahip_batch_attach)
+	void adopt(void *dev, size_t bytes) { release(); p = dev; cap = bytes; ext = true; }
 	int ensure(size_t bytes)
 	{
-		if (bytes <= cap) return 0;
-		if (p) (void)hipFree(p);
-		p = nullptr; cap = 0;
+		if (bytes <= cap && !ext) return 0;
+		if (p && !ext) (void)hipFree(p);
+		p = nullptr; cap = 0; ext = false;
 		size_t want = bytes + bytes / 8 + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { fprintf(stderr, "[bwahip] hipMalloc(%zu) failed\n", want); return BWAHIP_ENOMEM; }
 		cap = want;
 		return 0;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	void release() { if (p && !ext) (void)hipFree(p); p = nullptr; cap = 0; ext = false; }
 	template <class T> T *as() const { return (T*)p; }
 };
 
@@ -160,6 +161,9 @@ DevOpt make_dev_opt(const bwahip_opt_t *o)
 	d.min_chain_weight = o->min_chain_weight; d.max_chain_extend = o->max_chain_extend;
 	d.mask_level = o->mask_level; d.drop_ratio = o->drop_ratio; d.mask_level_redun = o->mask_level_redun;
 	memcpy(d.mat, o->mat, 25);
+	d.T = o->T; d.flag = o->flag; d.pen_unpaired = o->pen_unpaired; d.max_ins = o->max_ins; d.max_matesw = o->max_matesw;
+	d.max_XA_hits = o->max_XA_hits; d.max_XA_hits_alt = o->max_XA_hits_alt; d.mapQ_coef_fac = o->mapQ_coef_fac;
+	d.XA_drop_ratio = o->XA_drop_ratio; d.mapQ_coef_len = o->mapQ_coef_len;
 	return d;
 }
 
@@ -451,6 +455,17 @@ int bwahip_batch_upload(bwahip_ctx *c, int n, const uint8_t *seq, const int64_t 
 	if ((rc = upload(c->d_seq, seq, (size_t)c->total_bases, c->stream))) return rc;
 	if ((rc = upload(c->d_off, off, (size_t)(n + 1) * 8, c->stream))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int bwahip_batch_attach(bwahip_ctx *c, int n, const uint8_t *seq_dev, const int64_t *off_dev, int max_len, int64_t total_bases)
+{
+	if (!c || n < 0 || (n && (!seq_dev || !off_dev)) || max_len < 0 || total_bases < 0) return BWAHIP_EINVAL;
+	if (max_len > BWAHIP_MAX_READ_LEN) return BWAHIP_ECAPACITY;
+	HIP_TRY(hipSetDevice(c->device));
+	c->n_reads = n; c->max_len = max_len; c->total_bases = total_bases;
+	c->d_seq.adopt((void*)seq_dev, (size_t)total_bases);
+	c->d_off.adopt((void*)off_dev, (size_t)(n + 1) * 8);
 	return 0;
 }
 

@@ -83,6 +83,91 @@ def write_fastq(path, reads, paired_second=None, qual=b"I"):
             f.write(b"\n+\n" + q + b"\n")
 
 
+def read_fasta_bases(path, lens, width=60):
+    """The bases of a FASTA written by write_fasta (headers and newlines stripped), without parsing line by line."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    out = np.empty(int(sum(lens)), dtype=np.uint8)
+    o = p = 0
+    for c, ln in enumerate(lens):
+        p += len(b">ctg%d\n" % (c + 1))
+        full = (ln // width) * width
+        if full:
+            out[o:o + full] = raw[p:p + (full // width) * (width + 1)].reshape(-1, width + 1)[:, :width].reshape(-1)
+            p += (full // width) * (width + 1)
+        if ln > full:
+            out[o + full:o + ln] = raw[p:p + ln - full]
+            p += ln - full + 1
+        o += ln
+    return out
+
+
+def fixed_names(n, paired):
+    """(n, 9) uint8: NUL-terminated fixed-width names r0000000..; mates of a pair share their name (bwamem_pair.c:386)."""
+    idx = np.arange(n, dtype=np.int64) >> (1 if paired else 0)
+    a = np.empty((n, 9), dtype=np.uint8)
+    a[:, 0] = ord("r")
+    for k in range(7):
+        a[:, 7 - k] = (idx // 10 ** k) % 10 + 48
+    a[:, 8] = 0
+    return a
+
+
+def write_fastq_fixed(prefix, reads, paired, qual=b"I"):
+    """FASTQ with the names of fixed_names(); PE: <prefix>_1.fq / _2.fq (even / odd rows).  Vectorised: fixed-size records."""
+    n, rl = reads.shape
+    names = fixed_names(n, paired)[:, :8]
+    outs = []
+    for m, sel in ([(1, slice(0, n, 2)), (2, slice(1, n, 2))] if paired else [(0, slice(0, n))]):
+        sub, nm = reads[sel], names[sel]
+        rec = np.empty((len(sub), 1 + 8 + 1 + rl + 3 + rl + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1:9] = nm; rec[:, 9] = 10
+        rec[:, 10:10 + rl] = sub
+        rec[:, 10 + rl:13 + rl] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 13 + rl:13 + 2 * rl] = qual[0]
+        rec[:, 13 + 2 * rl] = 10
+        fn = f"{prefix}_{m}.fq" if paired else f"{prefix}.fq"
+        rec.tofile(fn)
+        outs.append(fn)
+    return outs
+
+
+SEQ_DTYPE = np.dtype([("l_seq", "<i4"), ("id", "<i4"), ("name", "<u8"), ("comment", "<u8"), ("seq", "<u8"), ("qual", "<u8"), ("sam", "<u8"),
+                      ("l_name", "i1"), ("l_comment", "i1"), ("l_qual", "<i2"), ("pad", "<i4")])   # bseq1_t, bwa.h:58-63 (56 bytes)
+
+
+def process_seqs_bulk(bw, ctx, opt, names, reads, qual=b"I", n_processed=0, pes0=None):
+    """bwahip_process_seqs (== mem_process_seqs) on a big batch without per-read Python work: the bseq1_t array is laid out
+    with numpy.  names: (n, w) NUL-terminated rows; reads: (n, rl) ASCII.  Returns (seconds inside the call, SAM bytes)."""
+    import ctypes as C
+    import time
+    assert SEQ_DTYPE.itemsize == C.sizeof(bw.Seq) == 56
+    n, rl = reads.shape
+    seqbuf = np.ascontiguousarray(reads).copy()             # converted to 0..4 codes in place, as the reference does
+    names = np.ascontiguousarray(names)
+    qbuf = np.frombuffer(qual * rl + b"\0", dtype=np.uint8).copy()
+    arr = np.zeros(n, dtype=SEQ_DTYPE)
+    arr["l_seq"] = rl
+    arr["id"] = np.arange(n)
+    arr["name"] = names.ctypes.data + np.arange(n, dtype=np.uint64) * names.shape[1]
+    arr["seq"] = seqbuf.ctypes.data + np.arange(n, dtype=np.uint64) * rl
+    arr["qual"] = qbuf.ctypes.data
+    L = bw.lib()
+    t0 = time.time()
+    rc = L.bwahip_process_seqs(ctx._h, C.byref(opt), n_processed, n, C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), pes0)
+    dt = time.time() - t0
+    if rc != 0:
+        raise bw.BwahipError(f"bwahip_process_seqs failed: {bw.ERRORS.get(rc, rc)}")
+    out, ln = C.c_void_p(), C.c_int64()
+    rc = L.bwahip_seqs_take_sam(C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), n, C.byref(out), C.byref(ln))
+    if rc != 0:
+        raise bw.BwahipError(f"bwahip_seqs_take_sam failed: {bw.ERRORS.get(rc, rc)}")
+    sam = C.string_at(out, ln.value)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(out)
+    return dt, sam
+
+
 # ------------------------------------------------------------------------------------------ index broadcast
 def load_index_arrays(prefix):
     """Read a stock index file set into numpy arrays + metadata (format: bwt.c:385-462, bntseq.c:65-211)."""

@@ -195,6 +195,9 @@ int bwahip_align_batch(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, bwahip_s
  * pairing) with opt->n_threads host threads.  seqs[i].sam is malloc()ed, NUL terminated. */
 int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);
 
+/* Concatenate seqs[0..n).sam into one malloc()ed buffer (read order; *out_len bytes + a NUL) and free the per-read strings. */
+int bwahip_seqs_take_sam(bwahip_seq_t *seqs, int n, char **out, int64_t *out_len);
+
 /* ---- stage-level entry points (parity tests and bench) --------------------
  * Reads are given packed: `seq` holds the concatenated 0..4 codes, read i is seq[off[i] .. off[i+1]).
  * Results come back as "i64 record" streams in malloc()ed buffers (*out, *out_len int64 words) in the
@@ -212,6 +215,9 @@ int bwahip_run_stages(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, const uin
  * durations of the last run measured with HIP events on the launch stream, in launch order
  * (see bwahip_kernel_name). */
 int bwahip_batch_upload(bwahip_ctx *ctx, int n, const uint8_t *seq, const int64_t *off);
+/* The same for reads that already sit in HBM of the context's device (codes 0..4 concatenated, off_dev[0] == 0): nothing
+ * is copied, the buffers stay the caller's and must stay valid until the next upload / attach / destroy. */
+int bwahip_batch_attach(bwahip_ctx *ctx, int n, const uint8_t *seq_dev, const int64_t *off_dev, int max_len, int64_t total_bases);
 int bwahip_batch_run(bwahip_ctx *ctx, const bwahip_opt_t *opt, float *kernel_ms, int n_kernel_ms);
 int bwahip_batch_download(bwahip_ctx *ctx, bwahip_alnreg_v *regs_out);       /* regs of the last run */
 int bwahip_n_kernels(void);

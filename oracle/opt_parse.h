@@ -15,7 +15,7 @@
 #include <ctype.h>
 #include <unistd.h>
 
-#define OPT_GETOPT_STRING "5qpaMCSPVYjuk:c:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:W:x:G:h:y:K:X:"
+#define OPT_GETOPT_STRING "Z5qpaMCSPVYjuk:c:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:W:x:G:h:y:K:X:"
 
 typedef struct {
 	OPT_T *opt;
@@ -26,6 +26,7 @@ typedef struct {
 	int ignore_alt;          /* -j */
 	int smart_pe;            /* -p */
 	int has_pes0;            /* -I */
+	int align_only;          /* -Z (ours): time the per-read hot path only (worker1 / mem_align1_core), no finalisation, no SAM */
 	PES_T pes[4];
 	char rg_id[256];         /* ID: field of -R (bwa_set_rg, bwa.c:562-583) */
 } optparse_t;
@@ -80,6 +81,7 @@ static int optparse_one(optparse_t *x, int c, const char *arg)
 	case 'W': o->min_chain_weight = atoi(arg); s->min_chain_weight = 1; break;
 	case 'y': o->max_mem_intv = (uint64_t)atol(arg); s->max_mem_intv = 1; break;
 	case 'C': x->copy_comment = 1; break;
+	case 'Z': x->align_only = 1; break;
 	case 'K': x->fixed_chunk = atoi(arg); break;
 	case 'X': o->mask_level = (float)atof(arg); break;
 	case 'x': x->mode = arg; break;

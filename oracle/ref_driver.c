@@ -126,6 +126,22 @@ static int main_mem(int argc, char **argv)
 			int i;
 			if (n == 0) { free(seqs); break; }
 			if (!op.copy_comment) for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; } /* stock: no -C */
+			if (op.align_only) { /* -Z: the first half of mem_process_seqs only (bwamem.c:1225-1232): kt_for(worker1) == mem_align1_core per read */
+				extern void kt_for(int n_threads, void (*func)(void*,int,int), void *data, int n);
+				worker_t w;
+				double t0;
+				w.regs = malloc(n * sizeof(mem_alnreg_v));
+				w.opt = opt; w.bwt = idx->bwt; w.bns = idx->bns; w.pac = idx->pac; w.seqs = seqs; w.n_processed = n_processed; w.pes = 0;
+				w.aux = malloc(opt->n_threads * sizeof(smem_aux_t*));
+				for (i = 0; i < opt->n_threads; ++i) w.aux[i] = smem_aux_init();
+				t0 = now_s();
+				kt_for(opt->n_threads, worker1, &w, (opt->flag & MEM_F_PE) ? n >> 1 : n);
+				t_align += now_s() - t0;
+				for (i = 0; i < opt->n_threads; ++i) smem_aux_destroy(w.aux[i]);
+				free(w.aux);
+				for (i = 0; i < n; ++i) { free(w.regs[i].a); seqs[i].sam = 0; }
+				free(w.regs);
+			} else
 			{ double t0 = now_s(); mem_process_seqs(opt, idx->bwt, idx->bns, idx->pac, n_processed, n, seqs, op.has_pes0 ? op.pes : 0); t_align += now_s() - t0; }
 			n_processed += n;
 			for (i = 0; i < n; ++i) {
