@@ -217,16 +217,62 @@ struct FinLaunch {
 	uint8_t *pool; unsigned long long *pool_head; unsigned long long pool_cap;   // CIGAR / MD text: bump allocation
 	int *redo_list, *redo_n; uint8_t *big_z;     // tasks whose backtrack matrix / window exceed LDS (k_cigar_big)
 	// SAM text
-	const uint8_t *qual; const uint8_t *names; const int64_t *name_off; const uint8_t *comments; const int64_t *comment_off;   // per read (comments may be null)
+	const uint8_t *qual; const int64_t *qual_off;   // qualities: read r at qual + qual_off[r], or qual_off[r] < 0: none ('*')
+	const uint8_t *names; const int64_t *name_off; const uint8_t *comments; const int64_t *comment_off;   // per read (comments may be null)
 	const uint8_t *ctg_names; const int *ctg_name_off; const uint8_t *ctg_anno; const int *ctg_anno_off;
 	const uint8_t *rg_id; int rg_len;
-	int64_t *sam_len; const int64_t *sam_off; uint8_t *sam;    // per read length (pass 1), exclusive scan, text (pass 2)
+	int *sam_len; const int64_t *sam_off; uint8_t *sam;        // per read length (pass 1), exclusive scan, text (pass 2)
+	const DevAln **rec_list, **xa_list;          // per region slot: the read's record list / the XA members of the record being printed
 	int *err;
 };
 int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st);
 int launch_task_fill(const FinLaunch &a, hipStream_t st);
 int launch_cigar(const FinLaunch &a, int64_t n_tasks, hipStream_t st);
+int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st);   // the tasks k_cigar listed in redo_list; big_z: grid slabs of cigar_big_slab_bytes()
+size_t cigar_big_slab_bytes();
 int launch_sam(const FinLaunch &a, bool write, hipStream_t st);
+
+// ---- paired-end stages on the GPU (k_pair.hip): insert-size histogram, mate rescue, pairing ----
+struct DevPes { int low, high, failed, pad; double avg, std; };   // mem_pestat_t, bwa.h:167-171
+// what the SAM stage needs to know about one read of a pair (mem_sam_pe, bwamem_pair.c:276-419)
+struct PeRead {
+	int mode;          // 1: the pair was paired (bwamem_pair.c:311-384); 0: each end printed like a single-end read with its mate attached (397-418)
+	int h_reg;         // region whose alignment is h[i] (the record of the paired mode / the mate information), -1: unaligned
+	int alt_reg;       // paired mode: ALT hit printed as supplementary (bwamem_pair.c:371-377), else -1
+	int mapq;          // paired mode: q_se[i]
+	int extra_flag;    // 0x1 | 0x2 (proper pair)
+	int pad[3];
+};
+struct PairLaunch {
+	DevIndex ix; DevOpt opt;
+	int n_reads; const uint8_t *seq; const int64_t *off;
+	int64_t n_processed;
+	const double *logtab;
+	const DevReg *regs; const int64_t *reg_base; const int *reg_n;   // mem_align1_core's regions (k_extend)
+	unsigned *hist;                              // 4 x (max_ins + 1) insert-size counts (mem_pestat's isize[], as a histogram)
+	DevPes pes[4];
+	const double *pair_tab; int tab_off[4];      // per direction: .721*log(2*erfc(|ns|/sqrt2)) for dist = low..high, made by the host's libm
+	// mate rescue
+	int *nb;                                     // per read: regions within pen_unpaired of the best, capped at max_matesw (bwamem_pair.c:291-297)
+	int *pe_cap; const int64_t *pe_base;         // per read: capacity of its list after rescue, and the scan of it
+	DevReg *pe_regs; int *pe_n;                  // the lists mem_sam_pe works on
+	int *resc_list; int *resc_n;                 // pairs that need at least one Smith-Waterman
+	uint8_t *slab; size_t slab_stride;           // k_matesw: per-workgroup global scratch (reference window, column maxima, long-query working set)
+	unsigned long long *counters;                // [0] SW calls, [1] rescued regions
+	// pairing
+	const FinReg *fregs; const int *freg_n; const int *n_pri;   // after k_mark on the pe lists (fregs is written: sub / secondary updates of bwamem_pair.c:347-350, 359-365)
+	FinReg *fregs_w;
+	uint8_t *need; int *xa_owner; int *task_n, *rec_n; int *scr;
+	PeRead *pe_read;
+	int *err;
+};
+int launch_pestat(const PairLaunch &a, hipStream_t st);
+int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
+int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
+int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
+int launch_pair(const PairLaunch &a, hipStream_t st);
+size_t matesw_slab_bytes(int max_ins, int max_len);
+int launch_sam_pe(const FinLaunch &a, const PeRead *pe_read, bool write, hipStream_t st);
 
 // K3b: mem_flt_chained_seeds on the chains k_chain / k_chain_flt left (k_seedsw.hip)
 struct SeedSwLaunch {

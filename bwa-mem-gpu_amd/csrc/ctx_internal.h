@@ -1,0 +1,90 @@
+// Context of libbwahip (one GPU, one index resident in HBM, the batch buffers) -- shared by the host translation units
+// runtime.hip (hot path sequencing, C ABI) and final_rt.hip (finalisation / SAM sequencing).
+#pragma once
+#include "bwahip_internal.h"
+#include <string>
+
+// ------------------------------------------------------------------ small device helpers
+struct DevBuf {
+	void *p = nullptr; size_t cap = 0; bool ext = false;   // ext: caller-owned device memory (bwahip_batch_attach)
+	void adopt(void *dev, size_t bytes) { release(); p = dev; cap = bytes; ext = true; }
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap && !ext) return 0;
+		if (p && !ext) (void)hipFree(p);
+		p = nullptr; cap = 0; ext = false;
+		size_t want = bytes + bytes / 8 + 256;
+		if (hipMalloc(&p, want) != hipSuccess) { fprintf(stderr, "[bwahip] hipMalloc(%zu) failed\n", want); return BWAHIP_ENOMEM; }
+		cap = want;
+		return 0;
+	}
+	void release() { if (p && !ext) (void)hipFree(p); p = nullptr; cap = 0; ext = false; }
+	template <class T> T *as() const { return (T*)p; }
+};
+
+
+// Tuning knobs (hand-off thresholds of the heavy-read kernels).  Read from the environment ONCE, when the context is
+// created; bwahip_ctx_tune changes them afterwards (tests force every hand-off kernel onto ordinary reads that way).
+struct Knobs {
+	int intv_cap = 96;          // BWAHIP_INTV_CAP: initial per-read interval capacity (grown on overflow)
+	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
+	int heavy_mult = 10;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never)
+	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which k_chain_big takes the read (< 0: off)
+	int rank_sort_min = 192;    // BWAHIP_RANK_SORT_MIN: dedup lists at least this long try the wavefront rank sort
+	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
+	int ext_lds_window = 1 << 30;   // BWAHIP_EXT_LDS_WINDOW: reference windows above this go to k_extend_big (tests; default = the compiled LDS window)
+	int gpu_final = 1;          // BWAHIP_GPU_FINAL: 0 = finalisation of single-end batches on host threads (host_final.cpp) instead of the GPU kernels
+	int verbose = 0;            // BWAHIP_VERBOSE
+	const char *dump_ext = nullptr;   // BWAHIP_DUMP_EXT (diagnostic)
+	void from_env()
+	{
+		auto geti = [](const char *k, int &v) { if (const char *e = getenv(k)) v = atoi(e); };
+		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult);
+		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final);
+		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
+		dump_ext = getenv("BWAHIP_DUMP_EXT");
+		if (intv_cap < 2) intv_cap = 2;
+	}
+};
+
+struct bwahip_ctx {
+	bool external_index = false;
+	Knobs knobs;
+	std::string rg_id;                   // read-group id appended as RG:Z: to every record (bwa_rg_id, bwa.c:44); empty = none
+	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
+	int device = 0;
+	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+	HostIndex host = {};                 // host copy: contig table + packed reference (always owned); FM-index arrays only when loaded from files
+	DevIndex ix;
+	DevBuf d_bwt, d_sa, d_pac, d_anns;
+	// batch state
+	int n_reads = 0, max_len = 0;
+	int64_t total_bases = 0;
+	DevBuf d_seq, d_off, d_seq4, d_smem_heavy, d_raw, d_raw_n;
+	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
+	DevBuf d_misc;                       // CNT_SLOTS rows of CNT_N counters (u64), then queue (4 x u32), err (i32)
+	// K3/K4 working set (sized from the seed count of the batch)
+	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
+	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t;
+	// finalisation on the GPU (final_rt.hip)
+	DevBuf d_ctg_names, d_ctg_name_off, d_ctg_anno, d_ctg_anno_off, d_rg;      // contig names / annotations (SAM RNAME, XR), read-group id
+	DevBuf d_qual, d_qual_off, d_names, d_name_off, d_comments, d_comment_off; // per-batch text inputs of the SAM kernels
+	DevBuf d_fregs, d_fregs2, d_fscr, d_need, d_xa_owner, d_freg_n, d_npri, d_task_n, d_rec_n, d_task_base, d_tasks, d_aln_of_reg, d_alns;
+	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
+	int64_t total_tasks = 0, total_sam = 0;
+	size_t pool_cap = 0;
+	float final_ms[8] = { 0 };           // k_mark, k_cigar, k_sam(size), k_sam(write) of the last run
+	int intv_cap = 96;                   // current capacity (starts at knobs.intv_cap, grows on overflow)
+	int64_t total_seeds = 0, total_regs = 0;
+	hipEvent_t ev[24];
+	float last_ms[24];
+};
+
+
+int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st);   // exclusive scan int32 -> int64, n+1 outputs
+int dev_upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st);
+int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump);      // the hot path over the uploaded batch
+int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bool timed);   // regions in HBM -> SAM text in HBM (single-end)
+int final_setup(bwahip_ctx *c);                                                       // contig name tables for the SAM kernels

@@ -1027,7 +1027,8 @@ static int sam_pe(const Opt &o, const Ref &ref, const PeStat pes[4], uint64_t id
 } // namespace hf
 
 // ================================================================ C ABI: bwahip_process_seqs == mem_process_seqs (bwamem.c:1215)
-extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
+// Host finalisation after the GPU hot path: paired-end batches (until mem_sam_pe moves to the GPU) and the gpu_final = 0 knob.
+int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
 {
 	if (!ctx || !opt || n < 0 || (n && !seqs)) return BWAHIP_EINVAL;
 	const bool pe = (opt->flag & BWAHIP_F_PE) != 0;

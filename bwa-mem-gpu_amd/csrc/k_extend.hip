@@ -22,6 +22,7 @@
 // lists (previous regions, overlapping seeds) use one lane per element and a ballot.
 #include "bwahip_internal.h"
 #include "wave_dev.h"
+#include "regsort_dev.h"
 
 namespace {
 using namespace wv;
@@ -256,109 +257,6 @@ __device__ __forceinline__ int cal_max_gap(const DevOpt &o, int qlen)           
 	l = l > 1 ? l : 1;
 	return l < o.w << 1 ? l : o.w << 1;
 }
-
-// ---- comparators of bwamem.c:398-402 on an index array into the read's DevReg list; exact introsort ----
-// The sort keys are copied out of the 80-byte records into a dense 16-byte array first (by all lanes): the sorts run on
-// one lane, and what they wait for is the latency of the key fetches.
-struct RegKey { int64_t k64; int score, qb; };               // mode 0: k64 = re; mode 1: k64 = rb
-struct RegSort { const RegKey *key; int mode; };              // mode 0: by re (mem_ars2); 1: score desc, rb, qb (mem_ars)
-__device__ __forceinline__ bool reg_lt(const RegSort s, int x, int y)
-{
-	const RegKey p = s.key[x], q = s.key[y];
-	if (s.mode == 0) return p.k64 < q.k64;
-	return p.score > q.score || (p.score == q.score && (p.k64 < q.k64 || (p.k64 == q.k64 && p.qb < q.qb)));
-}
-// Sort by ranks with the whole wavefront when no two keys are equal (then every correct sort, the reference's unstable
-// introsort included, produces the same order); returns false, leaving idx untouched, as soon as a tie exists -- the
-// caller then runs the exact introsort on one lane.  Only worth it for long lists.
-__device__ __forceinline__ bool wave_rank_sort(const RegSort c, int n, int *idx, int l)
-{
-	for (int base = 0; base < n; base += 64) {
-		const int t = base + l;
-		int rank = 0;
-		bool tie = false;
-		if (t < n) {
-			const RegKey kt = c.key[t];
-			for (int u = 0; u < n; ++u) {
-				const RegKey ku = c.key[u];
-				bool lt_ut, eq;
-				if (c.mode == 0) { lt_ut = ku.k64 < kt.k64; eq = ku.k64 == kt.k64; }
-				else {
-					eq = ku.score == kt.score && ku.k64 == kt.k64 && ku.qb == kt.qb;
-					lt_ut = ku.score > kt.score || (ku.score == kt.score && (ku.k64 < kt.k64 || (ku.k64 == kt.k64 && ku.qb < kt.qb)));
-				}
-				rank += lt_ut ? 1 : 0;
-				tie |= eq && u != t;
-			}
-		}
-		if (__ballot(tie)) return false;                     // idx[0..n) has not been touched
-		if (t < n) idx[n + rank] = t;                        // second half of idx is free (2 ints per seed slot)
-	}
-	__threadfence_block(); __syncthreads();
-	for (int i = l; i < n; i += 64) idx[i] = idx[n + i];
-	return true;
-}
-
-__device__ __forceinline__ void rs_insertion(const RegSort c, int *s, int *t)
-{
-	for (int *i = s + 1; i < t; ++i)
-		for (int *j = i; j > s && reg_lt(c, *j, *(j - 1)); --j) { int tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
-}
-__device__ __forceinline__ void rs_comb(const RegSort c, int n, int *a)
-{
-	const double shrink = 1.2473309501039786540366528676643;
-	int swapped, gap = n;
-	do {
-		if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
-		swapped = 0;
-		for (int *i = a; i < a + n - gap; ++i) {
-			int *j = i + gap;
-			if (reg_lt(c, *j, *i)) { int tmp = *i; *i = *j; *j = tmp; swapped = 1; }
-		}
-	} while (swapped || gap > 2);
-	if (gap != 1) rs_insertion(c, a, a + n);
-}
-// `budget` bounds the work so that a logic error can never hang the GPU: on exhaustion the sort stops and
-// the kernel reports BWAHIP_EINTERNAL (never expected; n log n comparisons suffice)
-__device__ __forceinline__ void rs_introsort(const RegSort c, int n, int *a, int *stk, int *bad)   // ksort.h:176-227
-{
-	int d, top = 0, *s, *t, *i, *j, *k, pivot, tmp;
-	long budget = 64L * n * 32 + 1024;
-	if (n < 1) return;
-	if (n == 2) { if (reg_lt(c, a[1], a[0])) { tmp = a[0]; a[0] = a[1]; a[1] = tmp; } return; }
-	for (d = 2; 1 << d < n; ++d);
-	s = a; t = a + (n - 1); d <<= 1;
-	for (;;) {
-		if (--budget < 0) { *bad = 1; return; }
-		if (s < t) {
-			if (--d == 0) { rs_comb(c, (int)(t - s) + 1, s); t = s; continue; }
-			i = s; j = t; k = i + ((j - i) >> 1) + 1;
-			if (reg_lt(c, *k, *i)) { if (reg_lt(c, *k, *j)) k = j; }
-			else k = reg_lt(c, *j, *i) ? i : j;
-			pivot = *k;
-			if (k != t) { tmp = *k; *k = *t; *t = tmp; }
-			for (;;) {
-				do ++i; while (i < t && reg_lt(c, *i, pivot));       // i stops at the pivot (at t) at the latest
-				do --j; while (i <= j && reg_lt(c, pivot, *j));
-				if (j <= i) break;
-				if (--budget < 0) { *bad = 2; return; }
-				tmp = *i; *i = *j; *j = tmp;
-			}
-			tmp = *i; *i = *t; *t = tmp;
-			if (i - s > t - i) {
-				if (i - s > 16) { stk[3*top] = (int)(s - a); stk[3*top+1] = (int)(i - 1 - a); stk[3*top+2] = d; ++top; }
-				s = t - i > 16 ? i + 1 : t;
-			} else {
-				if (t - i > 16) { stk[3*top] = (int)(i + 1 - a); stk[3*top+1] = (int)(t - a); stk[3*top+2] = d; ++top; }
-				t = i - s > 16 ? i - 1 : s;
-			}
-		} else {
-			if (top == 0) { rs_insertion(c, a, a + n); return; }
-			--top; s = a + stk[3*top]; t = a + stk[3*top+1]; d = stk[3*top+2];
-		}
-	}
-}
-
 
 // Window of the reference any seed of the chain could reach (bwamem.c:649-664), clamped to the contig of the first
 // seed as bns_fetch_seq does (bntseq.c:426), loaded into LDS as one base per byte.  false: window larger than MAXT.

@@ -11,12 +11,12 @@
 // Floating point: mapQ uses log(l), log(sub_n+1), log(seedcov) of integers -- read from a table the host filled with
 // glibc's log -- and plain IEEE double arithmetic otherwise (-ffp-contract=off).  Integer DP: MFMA not applicable.
 #include "bwahip_internal.h"
+#include "wave_dev.h"
+#include "final_dev.h"
 
 namespace {
-
-__device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ void wsync() { __threadfence_block(); __syncthreads(); }
-__device__ __forceinline__ int wsum(int v) { for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d); return v; }
+using namespace wv;
+using namespace fin;
 
 __device__ __forceinline__ uint64_t hash_64(uint64_t key)      // utils.h:97
 {
@@ -154,9 +154,8 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 		wsync();
 	}
 	if (l == 0) a.n_pri[r] = n_pri;
-	if (!PLAN) return;
 
-	// ---- mem_reorder_primary5 (bwamem.c:988-1010), -5
+	// ---- mem_reorder_primary5 (bwamem.c:988-1010), -5 (both the single-end path, bwamem.c:1205, and mem_sam_pe, bwamem_pair.c:305)
 	if (opt.flag & BWAHIP_F_PRIMARY5) {
 		if (l == 0) {
 			int np = 0, left_st = 0x7fffffff, left_k = -1;
@@ -177,42 +176,10 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 		}
 		wsync();
 	}
+	if (!PLAN) return;
 
-	// ---- selection: mem_gen_alt's XA membership (bwamem_extra.c:116-145) and mem_reg2sam's record filter (bwamem.c:1025-1031)
-	uint8_t *need = a.need + rb0;
-	int *owner = a.xa_owner + rb0;
-	int *cnt = z, *has_alt = z + n;                             // z is free now (2n of the 4n scratch ints)
-	for (int i = l; i < n; i += 64) { cnt[i] = 0; has_alt[i] = 0; need[i] = 0; owner[i] = -1; }
-	wsync();
-	const bool want_xa = !(opt.flag & BWAHIP_F_ALL);
-	if (want_xa) {
-		for (int i = l; i < n; i += 64) {
-			const int k = f[i].secondary_all;
-			int pr = -1;
-			if (k >= 0 && (double)f[i].score >= (double)f[k].score * (double)opt.XA_drop_ratio) pr = k;   // get_pri_idx: int >= int * double
-			owner[i] = pr;
-			if (pr >= 0) { atomicAdd(&cnt[pr], 1); if (f[i].is_alt) atomicOr(&has_alt[pr], 1); }
-		}
-		wsync();
-	}
-	int n_task = 0, n_rec = 0;
-	for (int base = 0; base < n; base += 64) {
-		const int i = base + l;
-		int nd = 0;
-		if (i < n) {
-			const FinReg p = f[i];
-			bool rec = p.score >= opt.T;
-			if (rec && p.secondary >= 0 && (p.is_alt || !(opt.flag & BWAHIP_F_ALL))) rec = false;
-			if (rec && p.secondary >= 0 && p.secondary < 0x7fffffff && (float)p.score < (float)f[p.secondary].score * opt.drop_ratio) rec = false;
-			if (rec) nd |= NEED_REC;
-			const int pr = owner[i];
-			if (want_xa && pr >= 0 && !(cnt[pr] > opt.max_XA_hits_alt || (!has_alt[pr] && cnt[pr] > opt.max_XA_hits))) nd |= NEED_XA;
-			else owner[i] = -1;
-			need[i] = (uint8_t)nd;
-		}
-		n_task += __popcll(__ballot(nd != 0));
-		n_rec += __popcll(__ballot((nd & NEED_REC) != 0));
-	}
+	int n_task, n_rec;
+	select_records(opt, n, f, a.need + rb0, a.xa_owner + rb0, z, l, n_task, n_rec);
 	if (l == 0) { a.task_n[r] = n_task; a.rec_n[r] = n_rec; }
 }
 
@@ -230,6 +197,343 @@ __global__ void k_task_fill(FinLaunch a)
 	}
 }
 
+// ===================================================================================================
+// K8 -- mem_reg2aln per selected region
+// ===================================================================================================
+constexpr int CG_MAXQ = BWAHIP_MAX_READ_LEN;
+constexpr int CG_MAXT = 1536;                                // reference span of a region kept in LDS
+constexpr int CG_ZLDS = 12288;                               // backtrack matrix bytes kept in LDS
+constexpr int CG_MAXC = 512;                                 // CIGAR operations staged in LDS
+constexpr int CG_MAXMD = 1024;                               // MD bytes staged in LDS
+constexpr int CG_BIG_T = 8192;                               // k_cigar_big: reference span / matrix rows in its global slab
+constexpr size_t CG_BIG_Z = (size_t)(CG_MAXQ + 1) * CG_BIG_T;
+
+// ksw_global2 (ksw.c:504-584) with the backtrack matrix z (one byte per band cell, ksw.c:551-572).  Same column layout
+// and max-plus scan for F as wave_global_score in k_extend.hip.  Returns the score.
+template <int CPL>
+__device__ int wave_global_trace(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col)
+{
+	const int l = lane(), j0 = l * CPL;
+	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
+	int qv[CPL], Hs[CPL], E[CPL];
+#pragma unroll
+	for (int c = 0; c < CPL; ++c) {
+		const int j = j0 + c;
+		qv[c] = j < qlen ? q[j * qs] : 4;
+		Hs[c] = j == 0 ? 0 : (j <= qlen && j <= w) ? -(sw.o_ins + e_ins * j) : NEG;   // ksw.c:523-526
+		E[c] = NEG;
+	}
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = t[i * ts];
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const int h1 = beg == 0 ? -(sw.o_del + e_del * (i + 1)) : NEG;
+		int M[CPL], u[CPL], P = LOW;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			M[c] = Hs[c] + sw.mat[tb * 5 + qv[c]];
+			u[c] = inb ? M[c] - oe_ins + j * e_ins : LOW;
+			P = P > u[c] ? P : u[c];
+		}
+		int run = wscan_excl_max(P, LOW);
+		int h[CPL];
+		uint8_t *zi = z + (size_t)i * n_col;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			int f = NEG - (j - beg) * e_ins;
+			const int g = run - (j - 1) * e_ins;
+			if (j > beg && run > LOW) f = f > g ? f : g;
+			int d = M[c] >= E[c] ? 0 : 1;
+			int hv = M[c] >= E[c] ? M[c] : E[c];
+			d = hv >= f ? d : 2;
+			hv = hv >= f ? hv : f;
+			h[c] = hv;
+			if (inb) {
+				const int tD = M[c] - oe_del;
+				int en = E[c] - e_del;
+				d |= en > tD ? 1 << 2 : 0;
+				en = en > tD ? en : tD;
+				E[c] = en;
+				const int tI = M[c] - oe_ins;
+				d |= f - e_ins > tI ? 2 << 4 : 0;
+				zi[j - beg] = (uint8_t)d;
+			}
+			run = run > u[c] ? run : u[c];
+		}
+		const int up = __builtin_amdgcn_update_dpp(0, h[CPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+#pragma unroll
+		for (int c = CPL - 1; c >= 0; --c) {
+			const int j = j0 + c;
+			const int left = c == 0 ? up : h[c - 1];
+			if (j == beg) Hs[c] = h1;
+			else if (j > beg && j <= end) Hs[c] = left;
+			if (j == end) E[c] = NEG;                             // ksw.c:582
+		}
+		if (end == beg) {
+#pragma unroll
+			for (int c = 0; c < CPL; ++c) if (j0 + c == end) Hs[c] = h1;
+		}
+	}
+	int score = LOW;
+#pragma unroll
+	for (int c = 0; c < CPL; ++c) if (j0 + c == qlen) score = Hs[c];
+	return wmax(score);
+}
+
+__device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q, int r)   // bwamem.c:799
+{
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	int w = (int)(((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.));
+	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
+	if (w < d) w = d;
+	return w;
+}
+
+// decimal digits of a non-negative integer into dst; returns the count
+__device__ __forceinline__ int put_uint(uint8_t *dst, unsigned v)
+{
+	char b[12]; int n = 0;
+	do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	for (int i = 0; i < n; ++i) dst[i] = (uint8_t)b[n - 1 - i];
+	return n;
+}
+
+struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; };
+
+// One task: region `ar` of read r -> DevAln (+ CIGAR words and MD text appended to the pool).  BIG: window / matrix in the
+// workgroup's global slab.  Returns false when the task does not fit this variant (caller lists it for k_cigar_big).
+template <bool BIG>
+__device__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, const CigarLds &m, int t_cap, size_t z_cap, DevAln *out)
+{
+	const int l = lane();
+	const DevOpt &opt = a.opt;
+	const DevIndex &ix = a.ix;
+	const int64_t l_pac = ix.l_pac;
+	const int l_query = (int)(a.off[r + 1] - a.off[r]);
+	const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+	const int64_t rb = ar.rb, re = ar.re;
+	const int rlen = (int)(re - rb);
+	if (lq <= 0 || rb >= re || (rb < l_pac && re > l_pac)) { if (l == 0) atomicExch(a.err, 30); return true; }   // bwa_gen_cigar2 would return NULL: never for regions of mem_align1_core
+	if (rlen > t_cap) return false;
+	const bool rev = rb >= l_pac;
+	int bad = 0;
+	DevAln al;
+	al.flag = ar.secondary >= 0 ? 0x100 : 0;
+	al.mapq = ar.secondary < 0 ? (uint32_t)approx_mapq_se(opt, a.logtab, ar, &bad) & 0xff : 0;
+	if (bad && l == 0) atomicExch(a.err, 31);
+	// reference span, one base per byte; for a reverse-strand hit query and reference are both read backwards (bwa.c:275-280)
+	__syncthreads();
+	for (int i = l; i < rlen; i += 64) m.t[i] = (uint8_t)ref_base(ix, rb + i);
+	__syncthreads();
+	const uint8_t *qp = rev ? m.q + qe - 1 : m.q + qb; const int qs = rev ? -1 : 1;
+	const uint8_t *tp = rev ? m.t + rlen - 1 : m.t; const int ts = rev ? -1 : 1;
+	Sw sw; sw.mat = m.mat; sw.o_del = opt.o_del; sw.e_del = opt.e_del; sw.o_ins = opt.o_ins; sw.e_ins = opt.e_ins; sw.mx = 0;
+	int w2;
+	{
+		const int tmp = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_del, opt.e_del);
+		w2 = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+		w2 = w2 > tmp ? w2 : tmp;
+		if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+	}
+	int score = 0, last_sc = -(1 << 30), n_cigar = 0, it = 0;
+	bool fits = true;
+	do {                                                         // bwamem.c:1124-1132
+		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+		// ---- bwa_gen_cigar2 (bwa.c:281-307)
+		if (lq == rlen && w2 == 0) {
+			int part = 0;
+			for (int i = l; i < lq; i += 64) part += m.mat[tp[i * ts] * 5 + qp[i * qs]];
+			score = wsum(part);
+			n_cigar = 1;
+			if (l == 0) m.cig[0] = (uint32_t)lq << 4 | 0;
+		} else {
+			int max_ins = div_plus1_trunc(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins);
+			int max_del = div_plus1_trunc(((lq + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del);
+			int max_gap = max_ins > max_del ? max_ins : max_del;
+			max_gap = max_gap > 1 ? max_gap : 1;
+			int dl = rlen - lq; dl = dl < 0 ? -dl : dl;
+			int w = (max_gap + dl + 1) >> 1;
+			w = w < w2 ? w : w2;
+			const int min_w = dl + 3;
+			w = w > min_w ? w : min_w;
+			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
+			if ((size_t)n_col * (size_t)rlen > z_cap) { fits = false; break; }
+			__syncthreads();
+			if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (lq < 128) score = wave_global_trace<2>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (lq < 192) score = wave_global_trace<3>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (lq < 256) score = wave_global_trace<4>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else score = wave_global_trace<11>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			wsync();
+			// ---- backtrack (ksw.c:586-603); operations are produced last to first and reversed afterwards
+			int nc = 0;
+			if (l == 0) {
+				int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
+				uint32_t cur = 0; bool have = false, ovf = false;
+				auto push = [&](int op, int len) {
+					if (have && (int)(cur & 0xf) == op) cur += (uint32_t)len << 4;
+					else { if (have) { if (nc < CG_MAXC) m.cig[nc] = cur; else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
+				};
+				while (i >= 0 && k >= 0) {
+					which = m.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+					if (which == 0) { push(0, 1); --i; --k; }
+					else if (which == 1) { push(2, 1); --i; }
+					else { push(1, 1); --k; }
+				}
+				if (i >= 0) push(2, i + 1);
+				if (k >= 0) push(1, k + 1);
+				if (have) { if (nc < CG_MAXC) m.cig[nc] = cur; else ovf = true; ++nc; }
+				if (ovf) nc = -1;
+				else for (int x = 0; x < nc >> 1; ++x) { const uint32_t tmp = m.cig[x]; m.cig[x] = m.cig[nc - 1 - x]; m.cig[nc - 1 - x] = tmp; }
+			}
+			nc = __shfl(nc, 0);
+			if (nc < 0) { fits = false; break; }
+			n_cigar = nc;
+			wsync();
+		}
+		if (score == last_sc || w2 == opt.w << 2) break;
+		last_sc = score;
+		w2 <<= 1;
+	} while (++it < 3 && score < ar.truesc - opt.a);
+	if (!fits) return false;
+
+	// ---- NM and MD (bwa.c:309-339) on the raw CIGAR; for a reverse-strand hit the bases come out complemented ("TGCAN")
+	int md_len = 0, NM = 0;
+	{
+		int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+		bool md_ovf = false;
+		auto emit_num = [&](int v) { if (md_len + 11 < CG_MAXMD) { if (l == 0) md_len += put_uint(m.md + md_len, (unsigned)v); } else md_ovf = true; };
+		// md_len is advanced by lane 0 only; it is broadcast after every variable-length emission
+		const char *int2base = rev ? "TGCAN" : "ACGTN";
+		for (int k = 0; k < n_cigar; ++k) {
+			const uint32_t cg = m.cig[k];
+			const int op = cg & 0xf, len = (int)(cg >> 4);
+			if (op == 0) {
+				for (int base = 0; base < len; base += 64) {
+					const int i = base + l;
+					const bool mm = i < len && qp[(x + i) * qs] != tp[(y + i) * ts];
+					unsigned long long mask = __ballot(mm);
+					int prev = 0;
+					while (mask) {
+						const int p = __ffsll((long long)mask) - 1;
+						mask &= mask - 1;
+						u += p - prev;
+						emit_num(u);
+						md_len = __shfl(md_len, 0);
+						if (md_len + 1 < CG_MAXMD) { if (l == 0) m.md[md_len] = (uint8_t)int2base[tp[(y + base + p) * ts]]; ++md_len; } else md_ovf = true;
+						++n_mm; u = 0; prev = p + 1;
+					}
+					const int chunk = len - base < 64 ? len - base : 64;
+					u += chunk - prev;
+				}
+				x += len; y += len;
+			} else if (op == 2) {
+				if (k > 0 && k < n_cigar - 1) {
+					emit_num(u);
+					md_len = __shfl(md_len, 0);
+					if (md_len + 1 + len < CG_MAXMD) {
+						if (l == 0) m.md[md_len] = '^';
+						for (int i = l; i < len; i += 64) m.md[md_len + 1 + i] = (uint8_t)int2base[tp[(y + i) * ts]];
+						md_len += 1 + len;
+					} else md_ovf = true;
+					u = 0; n_gap += len;
+				}
+				y += len;
+			} else if (op == 1) { x += len; n_gap += len; }
+		}
+		emit_num(u);
+		md_len = __shfl(md_len, 0);
+		NM = n_mm + n_gap;
+		if (md_ovf) return false;
+	}
+	wsync();
+	al.NM = (uint32_t)NM & 0x3fffff;
+	// ---- position, end deletions, clips (bwamem.c:1134-1168)
+	const int is_rev = rev ? 1 : 0;
+	int64_t pos = rev ? (l_pac << 1) - 1 - (re - 1) : rb;         // bns_depos(rb < l_pac ? rb : re - 1)
+	int c0 = 0, c1 = n_cigar;                                     // kept CIGAR words [c0, c1)
+	if (n_cigar > 0) {
+		if ((m.cig[0] & 0xf) == 2) { pos += m.cig[0] >> 4; c0 = 1; }
+		else if ((m.cig[n_cigar - 1] & 0xf) == 2) c1 = n_cigar - 1;
+	}
+	int clip5 = 0, clip3 = 0;
+	if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
+	const int n_out = (c1 - c0) + (clip5 ? 1 : 0) + (clip3 ? 1 : 0);
+	al.is_rev = (uint32_t)is_rev;
+	al.rid = dev_pos2rid(ix, pos);
+	al.pos = pos - ix.anns[al.rid].offset;
+	al.score = ar.score; al.sub = ar.sub > ar.csub ? ar.sub : ar.csub;
+	al.is_alt = (uint32_t)ar.is_alt; al.alt_sc = ar.alt_sc;
+	al.n_cigar = n_out; al.md_len = md_len; al.pad = 0;
+	// ---- CIGAR words + MD text into the pool
+	const unsigned long long bytes = ((unsigned long long)n_out * 4 + (unsigned long long)md_len + 7) & ~7ull;
+	unsigned long long at = 0;
+	if (l == 0) at = atomicAdd(a.pool_head, bytes);
+	at = (unsigned long long)__shfl((long long)at, 0);
+	if (at + bytes > a.pool_cap) { if (l == 0) atomicExch(a.err, 5); return true; }   // pool exhausted: the host re-runs the stage with a larger one
+	uint32_t *dc = reinterpret_cast<uint32_t*>(a.pool + at);
+	const int lead = clip5 ? 1 : 0;
+	if (l == 0) { if (clip5) dc[0] = (uint32_t)clip5 << 4 | 3; if (clip3) dc[n_out - 1] = (uint32_t)clip3 << 4 | 3; }
+	for (int i = l; i < c1 - c0; i += 64) dc[lead + i] = m.cig[c0 + i];
+	uint8_t *dm = a.pool + at + (size_t)n_out * 4;
+	for (int i = l; i < md_len; i += 64) dm[i] = m.md[i];
+	al.cigar_off = (int64_t)at; al.md_off = (int64_t)(at + (unsigned long long)n_out * 4);
+	if (l == 0) *out = al;
+	return true;
+}
+
+__global__ __launch_bounds__(64) void k_cigar(FinLaunch a, long long n_tasks)
+{
+	__shared__ uint8_t s_q[CG_MAXQ + 8];
+	__shared__ uint8_t s_t[CG_MAXT + 8];
+	__shared__ uint8_t s_z[CG_ZLDS];
+	__shared__ uint32_t s_cig[CG_MAXC];
+	__shared__ uint8_t s_md[CG_MAXMD];
+	__shared__ int8_t s_mat[32];
+	const long long t = blockIdx.x;
+	const int l = lane();
+	if (t >= n_tasks) return;
+	const int2 tk = a.tasks[t];
+	const int r = tk.x;
+	const int l_query = (int)(a.off[r + 1] - a.off[r]);
+	const uint8_t *query = a.seq + a.off[r];
+	for (int i = l; i < l_query; i += 64) { const uint8_t c = query[i]; s_q[i] = c < 5 ? c : 4; }   // bwamem.c:1115: codes >= 5 -> 4 (already codes here)
+	if (l < 25) s_mat[l] = a.opt.mat[l];
+	__syncthreads();
+	const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
+	const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat };
+	if (!reg2aln<false>(a, ar, r, m, CG_MAXT, CG_ZLDS, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
+}
+
+// tasks whose reference span, backtrack matrix, CIGAR or MD did not fit LDS: the same code on this workgroup's global slab
+__global__ __launch_bounds__(64) void k_cigar_big(FinLaunch a)
+{
+	__shared__ uint8_t s_q[CG_MAXQ + 8];
+	__shared__ uint32_t s_cig[CG_MAXC];
+	__shared__ uint8_t s_md[CG_MAXMD];
+	__shared__ int8_t s_mat[32];
+	const int l = lane();
+	uint8_t *slab = a.big_z + (size_t)blockIdx.x * (CG_BIG_Z + CG_BIG_T + 64);
+	const int n_redo = *a.redo_n;
+	for (int it = (int)blockIdx.x; it < n_redo; it += (int)gridDim.x) {
+		const long long t = a.redo_list[it];
+		const int2 tk = a.tasks[t];
+		const int r = tk.x;
+		const int l_query = (int)(a.off[r + 1] - a.off[r]);
+		const uint8_t *query = a.seq + a.off[r];
+		__syncthreads();
+		for (int i = l; i < l_query; i += 64) { const uint8_t c = query[i]; s_q[i] = c < 5 ? c : 4; }
+		if (l < 25) s_mat[l] = a.opt.mat[l];
+		__syncthreads();
+		const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
+		const CigarLds m = { s_q, slab + CG_BIG_Z, slab, s_cig, s_md, s_mat };
+		if (!reg2aln<true>(a, ar, r, m, CG_BIG_T, CG_BIG_Z, a.alns + t) && l == 0) { atomicExch(a.err, 6); atomicExch(a.err + 1, r); }
+	}
+}
+
 } // namespace
 
 int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st)
@@ -244,5 +548,20 @@ int launch_task_fill(const FinLaunch &a, hipStream_t st)
 {
 	if (a.n_reads <= 0) return 0;
 	hipLaunchKernelGGL(k_task_fill, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+size_t cigar_big_slab_bytes() { return CG_BIG_Z + CG_BIG_T + 64; }
+
+int launch_cigar(const FinLaunch &a, int64_t n_tasks, hipStream_t st)
+{
+	if (n_tasks <= 0) return 0;
+	hipLaunchKernelGGL(k_cigar, dim3((unsigned)n_tasks), dim3(64), 0, st, a, (long long)n_tasks);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_cigar_big, dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

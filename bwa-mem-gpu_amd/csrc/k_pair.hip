@@ -1,0 +1,602 @@
+// Paired-end stages on the GPU (the reference's mem_pestat + mem_sam_pe, bwamem_pair.c):
+//   k_pestat    per pair: the insert size mem_pestat would collect (bwamem_pair.c:72-97), as a histogram; the host turns
+//               the histogram into mem_pestat_t (percentiles, mean, sd: a few thousand numbers) and into the table of
+//               .721*log(2*erfc(|ns|/sqrt 2)) per distance that mem_pair needs (glibc's erfc / log, bwamem_pair.c:244).
+//   k_pe_prepare / k_pe_copy   capacities of the per-read lists after rescue; the pairs that need a Smith-Waterman.
+//   k_matesw    mem_matesw (bwamem_pair.c:137-206) for those pairs, one pair per wavefront, in the reference's order
+//               (the skip test looks at the list as rescued so far); ksw_align2 by the lane-exact striped SW of
+//               ssw_dev.h (byte kernel for reads under 250 bases); mem_sort_dedup_patch without patching afterwards.
+//   k_pair      mem_pair (bwamem_pair.c:208-272) and the decisions of mem_sam_pe (bwamem_pair.c:303-365, 397-411): which
+//               regions print, with which mapQ and flags.  Sorting inside mem_pair is on keys that cannot tie, so a
+//               rank sort gives the reference's order; of the list u only its top two elements and a count are needed.
+// Integer / table work throughout: MFMA not applicable.
+#include "bwahip_internal.h"
+#include "wave_dev.h"
+#include "regsort_dev.h"
+#include "ssw_dev.h"
+#include "final_dev.h"
+
+namespace {
+using namespace wv;
+using namespace fin;
+
+__device__ __forceinline__ uint64_t hash_64(uint64_t key)      // utils.h:97
+{
+	key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+	key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+	return key;
+}
+
+__device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)   // bwamem_pair.c:48
+{
+	const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+	const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+__device__ int cal_sub(const DevOpt &o, const DevReg *a, int n)   // bwamem_pair.c:58-70
+{
+	int j;
+	for (j = 1; j < n; ++j) {
+		const int b_max = a[j].qb > a[0].qb ? a[j].qb : a[0].qb;
+		const int e_min = a[j].qe < a[0].qe ? a[j].qe : a[0].qe;
+		if (e_min > b_max) {
+			const int min_l = a[j].qe - a[j].qb < a[0].qe - a[0].qb ? a[j].qe - a[j].qb : a[0].qe - a[0].qb;
+			if ((float)(e_min - b_max) >= (float)min_l * o.mask_level) break;
+		}
+	}
+	return j < n ? a[j].score : o.min_seed_len * o.a;
+}
+
+// ---------------------------------------------------------------------------------------------------- mem_pestat, device part
+__global__ void k_pestat(PairLaunch a)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= a.n_reads >> 1) return;
+	const int r0 = p << 1, r1 = r0 | 1;
+	const int n0 = a.reg_n[r0], n1 = a.reg_n[r1];
+	if (n0 == 0 || n1 == 0) return;
+	const DevReg *a0 = a.regs + a.reg_base[r0], *a1 = a.regs + a.reg_base[r1];
+	if ((double)cal_sub(a.opt, a0, n0) > 0.8 * a0[0].score) return;
+	if ((double)cal_sub(a.opt, a1, n1) > 0.8 * a1[0].score) return;
+	if (a0[0].rid != a1[0].rid) return;
+	int64_t is;
+	const int dir = infer_dir(a.ix.l_pac, a0[0].rb, a1[0].rb, &is);
+	if (is && is <= a.opt.max_ins) atomicAdd(&a.hist[(size_t)dir * (a.opt.max_ins + 1) + is], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------- rescue: preparation
+// per pair: nb[] (bwamem_pair.c:291-297: regions within pen_unpaired of the best one, at most max_matesw are used) and the
+// capacity of each list after rescue: every used region of the mate can add one region per live orientation
+__global__ void k_pe_prepare(PairLaunch a)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= a.n_reads >> 1) return;
+	int n_live = 0;
+	for (int d = 0; d < 4; ++d) n_live += a.pes[d].failed ? 0 : 1;
+	int nb[2];
+	for (int i = 0; i < 2; ++i) {
+		const int r = p << 1 | i, n = a.reg_n[r];
+		const DevReg *l = a.regs + a.reg_base[r];
+		int c = 0;
+		if (!(a.opt.flag & BWAHIP_F_NO_RESCUE) && n > 0) {
+			const int thr = l[0].score - a.opt.pen_unpaired;
+			for (int j = 0; j < n; ++j) c += l[j].score >= thr ? 1 : 0;   // the list is sorted by score: a prefix
+			c = c < a.opt.max_matesw ? c : a.opt.max_matesw;
+		}
+		nb[i] = c; a.nb[r] = c;
+	}
+	a.pe_cap[p << 1] = a.reg_n[p << 1] + nb[1] * n_live;
+	a.pe_cap[p << 1 | 1] = a.reg_n[p << 1 | 1] + nb[0] * n_live;
+}
+
+// skip mask of mem_matesw (bwamem_pair.c:143-150) for anchor `arb` against list ma[0..n): bit r set = orientation r needs no rescue
+__device__ __forceinline__ int skip_mask_seq(const PairLaunch &a, int64_t arb, const DevReg *ma, int n)
+{
+	int m = 0;
+	for (int d = 0; d < 4; ++d) m |= a.pes[d].failed ? 1 << d : 0;
+	for (int k = 0; k < n; ++k) {
+		int64_t dist;
+		const int d = infer_dir(a.ix.l_pac, arb, ma[k].rb, &dist);
+		if (dist >= a.pes[d].low && dist <= a.pes[d].high) m |= 1 << d;
+	}
+	return m;
+}
+
+// per pair: copy both lists into their (larger) slots; list the pair for k_matesw if any anchor has an orientation left
+__global__ void k_pe_copy(PairLaunch a)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= a.n_reads >> 1) return;
+	bool need = false;
+	for (int i = 0; i < 2; ++i) {
+		const int r = p << 1 | i, n = a.reg_n[r];
+		const DevReg *src = a.regs + a.reg_base[r];
+		DevReg *dst = a.pe_regs + a.pe_base[r];
+		for (int j = 0; j < n; ++j) dst[j] = src[j];
+		a.pe_n[r] = n;
+		const int m = r ^ 1;
+		const DevReg *ma = a.regs + a.reg_base[m];
+		for (int j = 0; j < a.nb[r] && !need; ++j) need = skip_mask_seq(a, src[j].rb, ma, a.reg_n[m]) != 15;
+	}
+	if (need) a.resc_list[atomicAdd(a.resc_n, 1)] = p;
+}
+
+// ---------------------------------------------------------------------------------------------------- mem_matesw
+constexpr int MS_MAXQ = BWAHIP_MAX_READ_LEN;
+constexpr int MS_LIST = 128;                                 // regions of a list kept in LDS while it is re-sorted
+
+struct MsLds {
+	uint8_t *q;                                                  // mate read (or its reverse complement), codes
+	int8_t *mat;
+	int8_t *prof; int16_t *h;                                    // striped-SW working set: 5 + 4 x 2 bytes per cell
+	RegKey *keys; int *idx; int *stk;                            // sort scratch (MS_LIST entries) -- longer lists use the global scratch
+};
+
+// mem_sort_dedup_patch with bns == 0 (no patching), as mem_matesw calls it (bwamem_pair.c:203; bwamem.c:444-496).
+// L: the list (n entries), tmp: a spare list of the same capacity, keys / idx: sort scratch (n and 2n entries).
+__device__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp, RegKey *keys, int *idx, int *stk, int l, int *err)
+{
+	if (n <= 1) return n;
+	for (int i = l; i < n; i += 64) { keys[i].k64 = L[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
+	wsync();
+	if (n < 64 || !wave_rank_sort(RegSort{keys, 0}, n, idx, l)) {
+		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, stk, &bad); if (bad) atomicExch(err, 40 + bad); }
+	}
+	wsync();
+	for (int i = l; i < n; i += 64) { tmp[i] = L[idx[i]]; tmp[i].n_comp = 1; }
+	wsync();
+	for (int i = l; i < n; i += 64) L[i] = tmp[i];
+	wsync();
+	if (l == 0) {                                                // redundancy (bwamem.c:451-480 without the patch branch)
+		for (int i = 1; i < n; ++i) {
+			DevReg *p = &L[i];
+			if (p->rid != L[i-1].rid || p->rb >= L[i-1].re + o.max_chain_gap) continue;
+			for (int j = i - 1; j >= 0 && p->rid == L[j].rid && p->rb < L[j].re + o.max_chain_gap; --j) {
+				DevReg *q = &L[j];
+				if (q->qe == q->qb) continue;
+				const int64_t orr = q->re - p->rb, oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+				const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+				const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+				if ((float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq) {
+					if (p->score < q->score) { p->qe = p->qb; break; }
+					else q->qe = q->qb;
+				}
+			}
+		}
+	}
+	wsync();
+	int m = 0;
+	for (int base = 0; base < n; base += 64) {                    // drop the excluded ones, order kept
+		const int i = base + l;
+		const bool keep = i < n && L[i].qe > L[i].qb;
+		const unsigned long long km = __ballot(keep);
+		if (keep) tmp[m + __popcll(km & ((1ull << l) - 1))] = L[i];
+		m += __popcll(km);
+	}
+	wsync();
+	n = m;
+	for (int i = l; i < n; i += 64) { L[i] = tmp[i]; keys[i].k64 = tmp[i].rb; keys[i].score = tmp[i].score; keys[i].qb = tmp[i].qb; idx[i] = i; }
+	wsync();
+	if (n < 64 || !wave_rank_sort(RegSort{keys, 1}, n, idx, l)) {
+		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, stk, &bad); if (bad) atomicExch(err, 50 + bad); }
+	}
+	wsync();
+	for (int i = l; i < n; i += 64) tmp[i] = L[idx[i]];
+	wsync();
+	m = 0;
+	for (int base = 0; base < n; base += 64) {                    // identical hits (bwamem.c:488-494)
+		const int i = base + l;
+		bool keep = i < n;
+		if (i > 0 && i < n) keep = !(tmp[i].score == tmp[i-1].score && tmp[i].rb == tmp[i-1].rb && tmp[i].qb == tmp[i-1].qb);
+		const unsigned long long km = __ballot(keep);
+		if (keep) L[m + __popcll(km & ((1ull << l) - 1))] = tmp[i];
+		m += __popcll(km);
+	}
+	wsync();
+	return m;
+}
+
+// mem_matesw (bwamem_pair.c:137-206): anchor `an` (a region of one end), mate read r_m (length l_ms), mate list L (n_ma).
+// P = 16: byte kernel (l_ms * a < 250), P = 8: word kernel.  Returns the new length of the mate list.
+template <int P>
+__device__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, DevReg *L, int n_ma, DevReg *tmp, RegKey *keys, int *idx,
+                      const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new)
+{
+	const DevOpt &opt = a.opt;
+	const DevIndex &ix = a.ix;
+	const int64_t l_pac = ix.l_pac;
+	int skip = 0;
+	for (int d = 0; d < 4; ++d) skip |= a.pes[d].failed ? 1 << d : 0;
+	for (int base = 0; base < n_ma; base += 64) {
+		const int k = base + l;
+		int d = 0; bool in = false;
+		if (k < n_ma) {
+			int64_t dist;
+			d = infer_dir(l_pac, an.rb, L[k].rb, &dist);
+			in = dist >= a.pes[d].low && dist <= a.pes[d].high;
+		}
+		for (int dd = 0; dd < 4; ++dd) if (__ballot(in && d == dd)) skip |= 1 << dd;
+	}
+	if (skip == 15) return n_ma;
+	const uint8_t *ms = a.seq + a.off[r_m];
+	int n = 0;
+	uint8_t *s_t = slab;                                          // reference window (global scratch of this workgroup)
+	for (int r = 0; r < 4; ++r) {
+		if (skip >> r & 1) continue;
+		const int is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);
+		int64_t rb, re;
+		if (!is_rev) {
+			rb = is_larger ? an.rb + a.pes[r].low : an.rb - a.pes[r].high;
+			re = (is_larger ? an.rb + a.pes[r].high : an.rb - a.pes[r].low) + l_ms;
+		} else {
+			rb = (is_larger ? an.rb + a.pes[r].low : an.rb - a.pes[r].high) - l_ms;
+			re = is_larger ? an.rb + a.pes[r].high : an.rb - a.pes[r].low;
+		}
+		if (rb < 0) rb = 0;
+		if (re > l_pac << 1) re = l_pac << 1;
+		int rid = -1;
+		if (rb < re) {                                            // bns_fetch_seq (bntseq.c:426): clamp to the contig holding the middle
+			const int64_t mid = (rb + re) >> 1;
+			const bool mrev = mid >= l_pac;
+			rid = dev_pos2rid(ix, mrev ? (l_pac << 1) - 1 - mid : mid);
+			int64_t far_beg = ix.anns[rid].offset, far_end = far_beg + ix.anns[rid].len;
+			if (mrev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+			rb = rb > far_beg ? rb : far_beg;
+			re = re < far_end ? re : far_end;
+		}
+		if (an.rid == rid && re - rb >= opt.min_seed_len) {
+			const int tlen = (int)(re - rb);
+			__syncthreads();
+			for (int i = l; i < tlen; i += 64) s_t[i] = (uint8_t)ref_base(ix, rb + i);
+			if (is_rev) for (int i = l; i < l_ms; i += 64) { const uint8_t c = ms[i]; m.q[l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
+			else for (int i = l; i < l_ms; i += 64) m.q[i] = ms[i];
+			wsync();
+			const int xtra = ssw::XSUBO | ssw::XSTART | (P == 16 ? ssw::XBYTE : 0) | (opt.min_seed_len * opt.a);
+			ssw::Res aln = { 0, -1, -1, -1, -1, -1, -1 };
+			if (l < P) {                                          // one group of the wavefront runs the alignment
+				const int cells = (l_ms + P - 1) / P * P;
+				ssw::Work w;
+				w.prof = m.prof; w.H0 = m.h; w.H1 = m.h + cells; w.E = m.h + 2 * cells; w.Hmax = m.h + 3 * cells;
+				w.colmax = reinterpret_cast<uint16_t*>(slab + ((size_t)tlen + 63) / 64 * 64);
+				aln = ssw::align2<P>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+			}
+			aln.score = __shfl(aln.score, 0); aln.te = __shfl(aln.te, 0); aln.qe = __shfl(aln.qe, 0); aln.score2 = __shfl(aln.score2, 0);
+			aln.tb = __shfl(aln.tb, 0); aln.qb = __shfl(aln.qb, 0);
+			++n_sw;
+			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {   // something goes wrong if aln.qb < 0 (bwamem_pair.c:178)
+				DevReg b;
+				memset(&b, 0, sizeof b);
+				b.rid = an.rid; b.is_alt = an.is_alt;
+				b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+				b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+				b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+				b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+				b.score = aln.score; b.csub = aln.score2;
+				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+				// insert b keeping the list sorted by score (bwamem_pair.c:194-199)
+				int at = n_ma;
+				for (int base = 0; base < n_ma; base += 64) {
+					const unsigned long long lower = __ballot(base + l < n_ma && L[base + l].score < b.score);
+					if (lower) { at = base + __ffsll((long long)lower) - 1; break; }
+				}
+				__syncthreads();
+				for (int hi = n_ma; hi > at; hi -= 64) {           // shift [at, n_ma) up by one, from the top, 64 at a time
+					const int i = hi - 1 - l;
+					DevReg v;
+					const bool mv = i >= at;
+					if (mv) v = L[i];
+					wsync();
+					if (mv) L[i + 1] = v;
+					wsync();
+				}
+				if (l == 0) L[at] = b;
+				++n_ma; ++n_new;
+				wsync();
+			}
+			++n;
+		}
+		if (n) n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, l, a.err);
+	}
+	return n_ma;
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
+{
+	constexpr int CELLS = P == 16 ? 256 : (MS_MAXQ + 7) / 8 * 8;
+	__shared__ uint8_t s_q[MS_MAXQ + 8];
+	__shared__ int8_t s_mat[32];
+	__shared__ int8_t s_prof[5 * CELLS];
+	__shared__ int16_t s_h[4 * CELLS];
+	__shared__ int s_stk[3 * 80];
+	const int l = lane();
+	if (l < 25) s_mat[l] = a.opt.mat[l];
+	__syncthreads();
+	uint8_t *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
+	unsigned long long n_sw = 0, n_new = 0;
+	const int n_resc = *a.resc_n;
+	for (int it = (int)blockIdx.x; it < n_resc; it += (int)gridDim.x) {
+		const int p = a.resc_list[it];
+		int n_list[2] = { a.pe_n[p << 1], a.pe_n[p << 1 | 1] };
+		// sort scratch of a list lives behind its slots' spare copy: tmp list, keys and index arrays sized by the capacity
+		for (int i = 0; i < 2; ++i) {
+			const int r = p << 1 | i, rm = r ^ 1;
+			const int l_ms = (int)(a.off[rm + 1] - a.off[rm]);
+			if ((P == 16) != (l_ms * a.opt.a < 250)) continue;    // the other instantiation takes this mate length
+			DevReg *L = a.pe_regs + a.pe_base[rm];
+			DevReg *tmp = a.pe_tmp + a.pe_base[rm];
+			RegKey *keys = a.pe_keys + a.pe_base[rm];
+			int *idx = a.pe_idx + 2 * a.pe_base[rm];
+			const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk };
+			const DevReg *snap = a.regs + a.reg_base[r];            // b[i]: the end's own regions as mem_align1_core left them
+			for (int j = 0; j < a.nb[r]; ++j)
+				n_list[i ^ 1] = matesw<P>(a, snap[j], rm, l_ms, L, n_list[i ^ 1], tmp, keys, idx, m, slab, l, n_sw, n_new);
+		}
+		if (l == 0) {
+			const int lm0 = (int)(a.off[(p << 1) + 1] - a.off[p << 1]), lm1 = (int)(a.off[(p << 1) + 2] - a.off[(p << 1) + 1]);
+			// each instantiation updates the list(s) it rescued into: list of read 1 is rescued with read 1's sequence (i = 0), list 0 with read 0's
+			if ((P == 16) == (lm1 * a.opt.a < 250)) a.pe_n[p << 1 | 1] = n_list[1];
+			if ((P == 16) == (lm0 * a.opt.a < 250)) a.pe_n[p << 1] = n_list[0];
+		}
+		__syncthreads();
+	}
+	if (l == 0 && n_sw) { atomicAdd(&a.counters[0], n_sw); atomicAdd(&a.counters[1], n_new); }
+}
+
+// ---------------------------------------------------------------------------------------------------- mem_pair + mem_sam_pe decisions
+struct PKey { uint64_t x, y; };
+__device__ __forceinline__ bool pk_lt(const PKey &a, const PKey &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
+__device__ __forceinline__ PKey wmax_pk(PKey v)
+{
+	for (int d = 32; d; d >>= 1) {
+		PKey o;
+		o.x = (uint64_t)__shfl_xor((long long)v.x, d); o.y = (uint64_t)__shfl_xor((long long)v.y, d);
+		if (pk_lt(v, o)) v = o;
+	}
+	return v;
+}
+
+#define RAW_MAPQ(diff, a) ((int)(6.02 * (diff) / (a) + .499))
+
+// One pair per wavefront.
+__global__ __launch_bounds__(64) void k_pair(PairLaunch a)
+{
+	const int p = blockIdx.x, l = lane();
+	const DevOpt &opt = a.opt;
+	const int64_t l_pac = a.ix.l_pac;
+	const int r0 = p << 1;
+	FinReg *f[2] = { a.fregs_w + a.pe_base[r0], a.fregs_w + a.pe_base[r0 | 1] };
+	const int nn[2] = { a.freg_n[r0], a.freg_n[r0 | 1] }, n_pri[2] = { a.n_pri[r0], a.n_pri[r0 | 1] };
+	uint8_t *need[2] = { a.need + a.pe_base[r0], a.need + a.pe_base[r0 | 1] };
+	int *owner[2] = { a.xa_owner + a.pe_base[r0], a.xa_owner + a.pe_base[r0 | 1] };
+	int *scr[2] = { a.scr + 4 * a.pe_base[r0], a.scr + 4 * a.pe_base[r0 | 1] };
+	PeRead pr[2];
+	for (int i = 0; i < 2; ++i) { pr[i].mode = 0; pr[i].h_reg = -1; pr[i].alt_reg = -1; pr[i].mapq = 0; pr[i].extra_flag = 1; pr[i].pad[0] = pr[i].pad[1] = pr[i].pad[2] = 0; }
+	bool paired = false;
+	int z[2] = { 0, 0 }, q_se[2] = { 0, 0 }, extra_flag = 1;
+
+	if (!(opt.flag & BWAHIP_F_NOPAIRING) && n_pri[0] && n_pri[1]) {
+		// ---- mem_pair (bwamem_pair.c:208-272).  v: the primary-assembly regions of both ends, sorted by (contig, forward position)
+		const int nv = n_pri[0] + n_pri[1];
+		PKey *v = reinterpret_cast<PKey*>(scr[0]);                  // 16 B x (cap0 + cap1) >= nv entries (the two reads' scratch is contiguous)
+		auto make_key = [&](int t) {
+			const int r = t < n_pri[0] ? 0 : 1, i = r ? t - n_pri[0] : t;
+			const FinReg &e = f[r][i];
+			PKey k;
+			k.x = e.rb < l_pac ? (uint64_t)e.rb : (uint64_t)((l_pac << 1) - 1 - e.rb);
+			k.x = (uint64_t)e.rid << 32 | (k.x - (uint64_t)a.ix.anns[e.rid].offset);
+			k.y = (uint64_t)e.score << 32 | (uint64_t)(i << 2) | (uint64_t)((e.rb >= l_pac) << 1) | (uint64_t)r;
+			return k;
+		};
+		for (int t = l; t < nv; t += 64) {
+			const PKey kt = make_key(t);
+			int rank = 0;
+			for (int u = 0; u < nv; ++u) rank += pk_lt(make_key(u), kt) ? 1 : 0;
+			v[rank] = kt;
+		}
+		wsync();
+		const int id = (int)((a.n_processed >> 1) + p);
+		// pass 1: the two largest elements of u (every admissible pair (k < i) with its score q and tie-breaking hash), and their number
+		PKey best = { 0, 0 }, second = { 0, 0 };
+		int cnt = 0;
+		auto for_pairs = [&](auto &&fn) {
+			for (int i = l; i < nv; i += 64) {
+				const PKey vi = v[i];
+				for (int r = 0; r < 2; ++r) {
+					const int dir = r << 1 | (int)(vi.y >> 1 & 1);
+					if (a.pes[dir].failed) continue;
+					const int which = r << 1 | (int)((vi.y & 1) ^ 1);
+					for (int k = i - 1; k >= 0; --k) {
+						const PKey vk = v[k];
+						if ((int)(vk.y & 3) != which) continue;
+						const int64_t dist = (int64_t)vi.x - (int64_t)vk.x;
+						if (dist > a.pes[dir].high) break;
+						if (dist < a.pes[dir].low) continue;
+						int q = (int)((double)((vi.y >> 32) + (vk.y >> 32)) + a.pair_tab[a.tab_off[dir] + (int)(dist - a.pes[dir].low)] * opt.a + .499);
+						if (q < 0) q = 0;
+						PKey u;
+						u.y = (uint64_t)k << 32 | (uint64_t)i;
+						u.x = (uint64_t)q << 32 | (hash_64(u.y ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU);
+						fn(u);
+					}
+				}
+			}
+		};
+		for_pairs([&](const PKey &u) {
+			++cnt;
+			if (cnt == 1 || pk_lt(best, u)) { if (cnt > 1) second = best; best = u; }
+			else if (cnt == 2 || pk_lt(second, u)) second = u;
+		});
+		// (best, second) per lane -> of the wavefront.  A lane with no pair offers {0,0}; real elements have y >= 1 (i >= 1)
+		const int n_u = wsum(cnt);
+		if (n_u > 0) {
+			const int my_cnt = cnt;
+			PKey mine = my_cnt ? best : PKey{ 0, 0 };
+			const PKey top = wmax_pk(mine);
+			const bool holder = my_cnt && mine.x == top.x && mine.y == top.y;
+			PKey off2 = holder ? (my_cnt > 1 ? second : PKey{ 0, 0 }) : mine;
+			const PKey sec = wmax_pk(off2);
+			int tmp = opt.a + opt.b;
+			tmp = tmp > opt.o_del + opt.e_del ? tmp : opt.o_del + opt.e_del;
+			tmp = tmp > opt.o_ins + opt.e_ins ? tmp : opt.o_ins + opt.e_ins;
+			const int ti = (int)(top.y & 0xffffffffu), tk = (int)(top.y >> 32);
+			z[v[ti].y & 1] = (int)((v[ti].y & 0xffffffffu) >> 2);
+			z[v[tk].y & 1] = (int)((v[tk].y & 0xffffffffu) >> 2);
+			const int o = (int)(top.x >> 32);
+			int subo = n_u > 1 ? (int)(sec.x >> 32) : 0, n_sub = 0;
+			{   // pass 2: bwamem_pair.c:266-268 -- all but the top element whose score is within tmp of subo
+				int c2 = 0;
+				for_pairs([&](const PKey &u) { if (subo - (int)(u.x >> 32) <= tmp) ++c2; });
+				n_sub = wsum(c2) - 1;
+			}
+			if (o > 0) {
+				// ---- bwamem_pair.c:312-365
+				int is_multi[2];
+				for (int i = 0; i < 2; ++i) {
+					int j;
+					for (j = 1; j < n_pri[i]; ++j) if (f[i][j].secondary < 0 && f[i][j].score >= opt.T) break;
+					is_multi[i] = j < n_pri[i] ? 1 : 0;
+				}
+				if (!(is_multi[0] || is_multi[1])) {
+					paired = true;
+					const int score_un = f[0][0].score + f[1][0].score - opt.pen_unpaired;
+					subo = subo > score_un ? subo : score_un;
+					int q_pe = RAW_MAPQ(o - subo, opt.a);
+					if (n_sub > 0) q_pe -= (int)(4.343 * a.logtab[n_sub + 1 < BWAHIP_LOGTAB_N ? n_sub + 1 : BWAHIP_LOGTAB_N - 1] + .499);
+					if (n_sub + 1 >= BWAHIP_LOGTAB_N && l == 0) atomicExch(a.err, 61);
+					if (q_pe < 0) q_pe = 0;
+					if (q_pe > 60) q_pe = 60;
+					q_pe = (int)(q_pe * (1. - .5 * (f[0][0].frac_rep + f[1][0].frac_rep)) + .499);
+					int bad = 0;
+					if (o > score_un) {                              // paired alignment is preferred
+						for (int i = 0; i < 2; ++i) {
+							FinReg c = f[i][z[i]];
+							if (c.secondary >= 0) {
+								c.sub = f[i][c.secondary].score; c.secondary = -2;
+								if (l == 0) { f[i][z[i]].sub = c.sub; f[i][z[i]].secondary = -2; }
+							}
+							q_se[i] = approx_mapq_se(opt, a.logtab, c, &bad);
+						}
+						wsync();
+						q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+						q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+						extra_flag |= 2;
+						for (int i = 0; i < 2; ++i) {
+							const int cap = RAW_MAPQ(f[i][z[i]].score - f[i][z[i]].csub, opt.a);
+							q_se[i] = q_se[i] < cap ? q_se[i] : cap;
+						}
+					} else {                                          // the unpaired alignment is preferred
+						z[0] = z[1] = 0;
+						q_se[0] = approx_mapq_se(opt, a.logtab, f[0][0], &bad);
+						q_se[1] = approx_mapq_se(opt, a.logtab, f[1][0], &bad);
+					}
+					if (bad && l == 0) atomicExch(a.err, 62);
+					for (int i = 0; i < 2; ++i) {                     // bwamem_pair.c:352-360
+						const int k = f[i][z[i]].secondary_all;
+						if (k >= 0 && k < n_pri[i]) {
+							wsync();
+							for (int j = l; j < nn[i]; j += 64) if (f[i][j].secondary_all == k || j == k) f[i][j].secondary_all = z[i];
+							wsync();
+							if (l == 0) f[i][z[i]].secondary_all = -1;
+							wsync();
+						}
+					}
+				}
+			}
+		}
+	}
+
+	if (paired) {
+		for (int i = 0; i < 2; ++i) {
+			const int n = nn[i];
+			// XA membership exactly as mem_gen_alt computes it over the whole list; only the members of the printed records are kept
+			int n_task, n_rec;
+			select_records(opt, n, f[i], need[i], owner[i], scr[i], l, n_task, n_rec);
+			wsync();
+			int alt_reg = -1;
+			if (n_pri[i] < n) {
+				const FinReg &q = f[i][n_pri[i]];
+				if (!(q.score < opt.T || q.secondary >= 0 || !q.is_alt)) alt_reg = n_pri[i];
+			}
+			int cnt_task = 0;
+			for (int base = 0; base < n; base += 64) {
+				const int j = base + l;
+				int nd = 0;
+				if (j < n) {
+					if (j == z[i] || j == alt_reg) nd |= NEED_REC;
+					if ((need[i][j] & NEED_XA) && (owner[i][j] == z[i] || owner[i][j] == alt_reg)) nd |= NEED_XA; else owner[i][j] = -1;
+					need[i][j] = (uint8_t)nd;
+				}
+				cnt_task += __popcll(__ballot(nd != 0));
+			}
+			pr[i].mode = 1; pr[i].h_reg = z[i]; pr[i].alt_reg = alt_reg; pr[i].mapq = q_se[i]; pr[i].extra_flag = extra_flag;
+			if (l == 0) { a.task_n[r0 | i] = cnt_task; a.rec_n[r0 | i] = 1 + (alt_reg >= 0 ? 1 : 0); }
+		}
+	} else {
+		// ---- no pairing (bwamem_pair.c:397-418): each end like a single-end read, with the mate's best hit attached
+		for (int i = 0; i < 2; ++i) {
+			const int n = nn[i];
+			int which = -1;
+			if (n > 0) {
+				if (f[i][0].score >= opt.T) which = 0;
+				else if (n_pri[i] < n && f[i][n_pri[i]].score >= opt.T) which = n_pri[i];
+			}
+			int n_task = 0, n_rec = 0;
+			if (n > 0) {
+				select_records(opt, n, f[i], need[i], owner[i], scr[i], l, n_task, n_rec);
+				wsync();
+				if (which >= 0 && need[i][which] == 0) { ++n_task; if (l == 0) need[i][which] = NEED_H; }   // h[i] of a region that prints nothing itself
+				wsync();
+			}
+			pr[i].mode = 0; pr[i].h_reg = which; pr[i].extra_flag = 1;
+			if (l == 0) { a.task_n[r0 | i] = n_task; a.rec_n[r0 | i] = n_rec; }
+		}
+	}
+	if (l == 0) { a.pe_read[r0] = pr[0]; a.pe_read[r0 | 1] = pr[1]; }
+}
+
+} // namespace
+
+size_t matesw_slab_bytes(int max_ins, int max_len)
+{
+	const size_t win = (size_t)max_ins + 2 * (size_t)max_len + 256;     // the widest reference window: high - low + l_ms
+	return ((win + 63) / 64 * 64) + win * 2 + 256;                      // + one 16-bit column maximum per window base
+}
+
+int launch_pestat(const PairLaunch &a, hipStream_t st)
+{
+	const int np = a.n_reads >> 1;
+	if (np <= 0) return 0;
+	hipLaunchKernelGGL(k_pestat, dim3((np + 255) / 256), dim3(256), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_pe_prepare(const PairLaunch &a, hipStream_t st)
+{
+	const int np = a.n_reads >> 1;
+	if (np <= 0) return 0;
+	hipLaunchKernelGGL(k_pe_prepare, dim3((np + 255) / 256), dim3(256), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_pe_copy(const PairLaunch &a, hipStream_t st)
+{
+	const int np = a.n_reads >> 1;
+	if (np <= 0) return 0;
+	hipLaunchKernelGGL(k_pe_copy, dim3((np + 255) / 256), dim3(256), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_matesw(const PairLaunch &a, int grid, hipStream_t st)
+{
+	if (grid <= 0) return 0;
+	hipLaunchKernelGGL(k_matesw<16>, dim3(grid), dim3(64), 0, st, a);   // mates under 250 bases: byte kernel
+	hipLaunchKernelGGL(k_matesw<8>, dim3(grid), dim3(64), 0, st, a);    // longer mates: word kernel (after the byte one: a pair may need both)
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_pair(const PairLaunch &a, hipStream_t st)
+{
+	const int np = a.n_reads >> 1;
+	if (np <= 0) return 0;
+	hipLaunchKernelGGL(k_pair, dim3(np), dim3(64), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}

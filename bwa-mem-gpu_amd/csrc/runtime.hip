@@ -1,28 +1,10 @@
 // Host runtime of libbwahip: context, HBM residency of the index, batch buffers, kernel sequencing
 // and the C ABI of include/bwahip.h.  One context drives one GPU from one host thread; multi-GPU
 // runs use one process (one context) per GPU and shard whole batches (DESIGN.md section "Multi-GPU").
-#include "bwahip_internal.h"
+#include "ctx_internal.h"
 #include <math.h>
 #include <algorithm>
 #include <atomic>
-
-// ------------------------------------------------------------------ small device helpers
-struct DevBuf {
-	void *p = nullptr; size_t cap = 0; bool ext = false;   // ext: caller-owned device memory (bwahip_batch_attach)
-	void adopt(void *dev, size_t bytes) { release(); p = dev; cap = bytes; ext = true; }
-	int ensure(size_t bytes)
-	{
-		if (bytes <= cap && !ext) return 0;
-		if (p && !ext) (void)hipFree(p);
-		p = nullptr; cap = 0; ext = false;
-		size_t want = bytes + bytes / 8 + 256;
-		if (hipMalloc(&p, want) != hipSuccess) { fprintf(stderr, "[bwahip] hipMalloc(%zu) failed\n", want); return BWAHIP_ENOMEM; }
-		cap = want;
-		return 0;
-	}
-	void release() { if (p && !ext) (void)hipFree(p); p = nullptr; cap = 0; ext = false; }
-	template <class T> T *as() const { return (T*)p; }
-};
 
 namespace {
 // exclusive scan int32 -> int64 (n+1 outputs) in three small launches: tile sums, scan of the tile sums, tile scans
@@ -85,6 +67,8 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_tiles(const int *in, const long
 	for (int i = 0; i < SCAN_PER; ++i) { if (b + i < n) out[b + i] = run; run += v[i]; }
 }
 
+} // namespace
+
 int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st)
 {
 	const int tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -95,59 +79,8 @@ int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st)
 	hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_T), 0, st, in, tmp.as<long long>(), out, n);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
-} // namespace
 
 static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec", "k_smem3", "k_intv_sort", "k_seed_sw" };
-
-// Tuning knobs (hand-off thresholds of the heavy-read kernels).  Read from the environment ONCE, when the context is
-// created; bwahip_ctx_tune changes them afterwards (tests force every hand-off kernel onto ordinary reads that way).
-struct Knobs {
-	int intv_cap = 96;          // BWAHIP_INTV_CAP: initial per-read interval capacity (grown on overflow)
-	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
-	int heavy_mult = 10;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never)
-	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which k_chain_big takes the read (< 0: off)
-	int rank_sort_min = 192;    // BWAHIP_RANK_SORT_MIN: dedup lists at least this long try the wavefront rank sort
-	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
-	int ext_lds_window = 1 << 30;   // BWAHIP_EXT_LDS_WINDOW: reference windows above this go to k_extend_big (tests; default = the compiled LDS window)
-	int verbose = 0;            // BWAHIP_VERBOSE
-	const char *dump_ext = nullptr;   // BWAHIP_DUMP_EXT (diagnostic)
-	void from_env()
-	{
-		auto geti = [](const char *k, int &v) { if (const char *e = getenv(k)) v = atoi(e); };
-		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult);
-		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window);
-		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
-		dump_ext = getenv("BWAHIP_DUMP_EXT");
-		if (intv_cap < 2) intv_cap = 2;
-	}
-};
-
-struct bwahip_ctx {
-	bool external_index = false;
-	Knobs knobs;
-	std::string rg_id;                   // read-group id appended as RG:Z: to every record (bwa_rg_id, bwa.c:44); empty = none
-	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
-	int device = 0;
-	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
-	HostIndex host = {};                 // host copy: contig table + packed reference (always owned); FM-index arrays only when loaded from files
-	DevIndex ix;
-	DevBuf d_bwt, d_sa, d_pac, d_anns;
-	// batch state
-	int n_reads = 0, max_len = 0;
-	int64_t total_bases = 0;
-	DevBuf d_seq, d_off, d_seq4, d_smem_heavy, d_raw, d_raw_n;
-	DevBuf d_intv, d_intv_n, d_seed_cnt, d_lrep, d_seed_base, d_seeds, d_scratch;
-	DevBuf d_misc;                       // CNT_SLOTS rows of CNT_N counters (u64), then queue (4 x u32), err (i32)
-	// K3/K4 working set (sized from the seed count of the batch)
-	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
-	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t;
-	int intv_cap = 96;                   // current capacity (starts at knobs.intv_cap, grows on overflow)
-	int64_t total_seeds = 0, total_regs = 0;
-	hipEvent_t ev[24];
-	float last_ms[24];
-};
 
 DevOpt make_dev_opt(const bwahip_opt_t *o)
 {
@@ -205,13 +138,16 @@ void bwahip_opt_fill_scmat(bwahip_opt_t *o)   // bwa_fill_scmat, bwa.c:249: call
 	for (int j = 0; j < 5; ++j) o->mat[k++] = -1;
 }
 
-static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
+} // extern "C"
+int dev_upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
 {
 	int rc = b.ensure(bytes ? bytes : 16);
 	if (rc) return rc;
 	if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
 	return 0;
 }
+static inline int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) { return dev_upload(b, src, bytes, st); }
+extern "C" {
 
 static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac)
 {
@@ -252,7 +188,7 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 	for (ix.sa_shift = 0; (1 << ix.sa_shift) < bwt->sa_intv; ++ix.sa_shift);
 	if ((1 << ix.sa_shift) != bwt->sa_intv) return BWAHIP_EINVAL;
 	if (bwt->bwt_size < ((bwt->seq_len + 127) / 128) * 16) return BWAHIP_EINVAL;   // every 128-base block must be present
-	return 0;
+	return final_setup(c);
 }
 
 int bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac, int device, bwahip_ctx **out)
@@ -320,7 +256,10 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t };
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t,
+	                   &c->d_ctg_names, &c->d_ctg_name_off, &c->d_ctg_anno, &c->d_ctg_anno_off, &c->d_rg, &c->d_qual, &c->d_qual_off, &c->d_names, &c->d_name_off, &c->d_comments, &c->d_comment_off,
+	                   &c->d_fregs, &c->d_fregs2, &c->d_fscr, &c->d_need, &c->d_xa_owner, &c->d_freg_n, &c->d_npri, &c->d_task_n, &c->d_rec_n, &c->d_task_base, &c->d_tasks, &c->d_aln_of_reg, &c->d_alns,
+	                   &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -351,6 +290,7 @@ int bwahip_ctx_tune(bwahip_ctx *c, const char *key, int value)
 	else if (!strcmp(key, "rank_sort_min")) k.rank_sort_min = value;
 	else if (!strcmp(key, "spec_min_chains")) k.spec_min_chains = value;
 	else if (!strcmp(key, "ext_lds_window")) k.ext_lds_window = value < 1 ? 1 : value;
+	else if (!strcmp(key, "gpu_final")) k.gpu_final = value;
 	else if (!strcmp(key, "verbose")) k.verbose = value;
 	else return BWAHIP_EINVAL;
 	return 0;
@@ -472,7 +412,9 @@ int bwahip_batch_attach(bwahip_ctx *c, int n, const uint8_t *seq_dev, const int6
 int bwahip_n_kernels(void) { return (int)(sizeof(g_kernel_names) / sizeof(g_kernel_names[0])); }
 const char *bwahip_kernel_name(int i) { return i >= 0 && i < bwahip_n_kernels() ? g_kernel_names[i] : ""; }
 
-static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
+} // extern "C" (the pipeline itself has C++ linkage: final_rt.hip calls it)
+
+int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 {
 	const bool verbose = c->knobs.verbose != 0;
 #define STAGE_LOG(name) do { if (verbose) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bwahip] %s done (%s)\n", name, hipGetErrorString(hipGetLastError())); fflush(stderr); } } while (0)
@@ -660,6 +602,8 @@ static int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool
 	}
 	return BWAHIP_EINTERNAL;
 }
+
+extern "C" {
 
 int bwahip_batch_run(bwahip_ctx *c, const bwahip_opt_t *opt, float *kernel_ms, int n_ms)
 {
