@@ -110,6 +110,7 @@ def lib():
     L.bwahip_align_batch.argtypes = [vp, C.POINTER(Opt), C.c_int, C.POINTER(Seq), C.POINTER(AlnRegV)]
     L.bwahip_process_seqs.argtypes = [vp, C.POINTER(Opt), C.c_int64, C.c_int, C.POINTER(Seq), C.POINTER(PeStat)]
     L.bwahip_batch_download.argtypes = [vp, C.POINTER(AlnRegV)]
+    L.bwahip_last_pe_stats.argtypes = [vp, C.POINTER(PeStat), u64p]
     L.bwahip_seqs_take_sam.argtypes = [C.POINTER(Seq), C.c_int, C.POINTER(vp), i64p]
     _lib = L
     return L
@@ -237,6 +238,13 @@ class Context:
             out.append(C.string_at(arr[i].sam))
             libc.free(C.cast(arr[i].sam, C.c_void_p))
         return out
+
+    def last_pe_stats(self):
+        """(pestat[4] as dicts, mate-rescue alignments run on the GPU, regions they added) of the last PE batch."""
+        pes = (PeStat * 4)()
+        cnt = (C.c_uint64 * 2)()
+        _check(lib().bwahip_last_pe_stats(self._h, pes, cnt), "bwahip_last_pe_stats")
+        return [dict(low=p.low, high=p.high, failed=p.failed, avg=p.avg, std=p.std) for p in pes], int(cnt[0]), int(cnt[1])
 
     def batch_upload(self, codes, off):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)

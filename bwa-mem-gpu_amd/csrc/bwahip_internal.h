@@ -196,7 +196,9 @@ struct DevAln {
 	int64_t md_off; int32_t md_len, pad;
 };
 // what a region is needed for (FinLaunch::need)
-enum { NEED_REC = 1 /* prints a SAM record */, NEED_XA = 2 /* listed in another record's XA tag */ };
+enum { NEED_REC = 1 /* prints a SAM record */, NEED_XA = 2 /* listed in another record's XA tag */, NEED_H = 4 /* only as the mate information of the other end (h[i], bwamem_pair.c:404) */ };
+struct DevPes { int low, high, failed, pad; double avg, std; };   // mem_pestat_t, bwa.h:167-171
+struct PeRead;
 
 struct FinLaunch {
 	DevIndex ix; DevOpt opt;
@@ -223,6 +225,7 @@ struct FinLaunch {
 	const uint8_t *rg_id; int rg_len;
 	int *sam_len; const int64_t *sam_off; uint8_t *sam;        // per read length (pass 1), exclusive scan, text (pass 2)
 	const DevAln **rec_list, **xa_list;          // per region slot: the read's record list / the XA members of the record being printed
+	const PeRead *pe_read; DevPes pes[4];        // paired-end batches: per-read decisions of k_pair, insert-size statistics
 	int *err;
 };
 int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st);
@@ -233,7 +236,6 @@ size_t cigar_big_slab_bytes();
 int launch_sam(const FinLaunch &a, bool write, hipStream_t st);
 
 // ---- paired-end stages on the GPU (k_pair.hip): insert-size histogram, mate rescue, pairing ----
-struct DevPes { int low, high, failed, pad; double avg, std; };   // mem_pestat_t, bwa.h:167-171
 // what the SAM stage needs to know about one read of a pair (mem_sam_pe, bwamem_pair.c:276-419)
 struct PeRead {
 	int mode;          // 1: the pair was paired (bwamem_pair.c:311-384); 0: each end printed like a single-end read with its mate attached (397-418)
@@ -256,6 +258,7 @@ struct PairLaunch {
 	int *nb;                                     // per read: regions within pen_unpaired of the best, capped at max_matesw (bwamem_pair.c:291-297)
 	int *pe_cap; const int64_t *pe_base;         // per read: capacity of its list after rescue, and the scan of it
 	DevReg *pe_regs; int *pe_n;                  // the lists mem_sam_pe works on
+	DevReg *pe_tmp; void *pe_keys; int *pe_idx;  // sort scratch of a list at its slots: spare list, 16-byte keys, 2 ints per slot
 	int *resc_list; int *resc_n;                 // pairs that need at least one Smith-Waterman
 	uint8_t *slab; size_t slab_stride;           // k_matesw: per-workgroup global scratch (reference window, column maxima, long-query working set)
 	unsigned long long *counters;                // [0] SW calls, [1] rescued regions
@@ -271,8 +274,8 @@ int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
 int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
 int launch_pair(const PairLaunch &a, hipStream_t st);
-size_t matesw_slab_bytes(int max_ins, int max_len);
-int launch_sam_pe(const FinLaunch &a, const PeRead *pe_read, bool write, hipStream_t st);
+size_t matesw_slab_bytes(int64_t window);
+int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st);
 
 // K3b: mem_flt_chained_seeds on the chains k_chain / k_chain_flt left (k_seedsw.hip)
 struct SeedSwLaunch {

@@ -34,13 +34,14 @@ struct Knobs {
 	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
 	int ext_lds_window = 1 << 30;   // BWAHIP_EXT_LDS_WINDOW: reference windows above this go to k_extend_big (tests; default = the compiled LDS window)
 	int gpu_final = 1;          // BWAHIP_GPU_FINAL: 0 = finalisation of single-end batches on host threads (host_final.cpp) instead of the GPU kernels
+	int gpu_pair = 1;           // BWAHIP_GPU_PAIR: 0 = paired-end batches finalised on host threads (mate rescue, pairing, SAM)
 	int verbose = 0;            // BWAHIP_VERBOSE
 	const char *dump_ext = nullptr;   // BWAHIP_DUMP_EXT (diagnostic)
 	void from_env()
 	{
 		auto geti = [](const char *k, int &v) { if (const char *e = getenv(k)) v = atoi(e); };
 		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult);
-		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final);
+		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final); geti("BWAHIP_GPU_PAIR", gpu_pair);
 		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
 		dump_ext = getenv("BWAHIP_DUMP_EXT");
 		if (intv_cap < 2) intv_cap = 2;
@@ -72,6 +73,9 @@ struct bwahip_ctx {
 	DevBuf d_ctg_names, d_ctg_name_off, d_ctg_anno, d_ctg_anno_off, d_rg;      // contig names / annotations (SAM RNAME, XR), read-group id
 	DevBuf d_qual, d_qual_off, d_names, d_name_off, d_comments, d_comment_off; // per-batch text inputs of the SAM kernels
 	DevBuf d_fregs, d_fregs2, d_fscr, d_need, d_xa_owner, d_freg_n, d_npri, d_task_n, d_rec_n, d_task_base, d_tasks, d_aln_of_reg, d_alns;
+	DevBuf d_hist, d_pair_tab, d_nb, d_pe_cap, d_pe_base, d_pe_regs, d_pe_n, d_pe_tmp, d_pe_keys, d_pe_idx, d_resc, d_ms_slab, d_pe_read;   // paired-end stages
+	bwahip_pestat_t last_pes[4];         // insert-size statistics of the last paired-end batch
+	unsigned long long last_pe_counters[2] = { 0, 0 };   // mate-rescue alignments run / regions added
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
 	int64_t total_tasks = 0, total_sam = 0;
 	size_t pool_cap = 0;
@@ -86,5 +90,5 @@ struct bwahip_ctx {
 int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st);   // exclusive scan int32 -> int64, n+1 outputs
 int dev_upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st);
 int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump);      // the hot path over the uploaded batch
-int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bool timed);   // regions in HBM -> SAM text in HBM (single-end)
+int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const bwahip_pestat_t *pes0, bool timed);   // regions in HBM -> SAM text in HBM (SE, or PE when opt->flag has MEM_F_PE)
 int final_setup(bwahip_ctx *c);                                                       // contig name tables for the SAM kernels

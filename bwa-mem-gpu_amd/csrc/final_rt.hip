@@ -4,6 +4,8 @@
 #include "ctx_internal.h"
 #include <atomic>
 #include <thread>
+#include <math.h>
+#include <algorithm>
 
 int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);   // host_final.cpp
 
@@ -27,14 +29,128 @@ int final_setup(bwahip_ctx *c)
 	return 0;
 }
 
-// K6 -> K9 over the batch run_pipeline left in HBM.  The text inputs (d_qual, d_names, ...) must be uploaded.
-int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bool timed)
+// mem_pestat (bwamem_pair.c:72-134) from the insert-size histogram the GPU collected: the sorted list of the reference is the
+// histogram read in ascending order, so percentiles, mean and (added in the same order) the sum of squares come out the same.
+static void pestat_from_hist(const bwahip_opt_t *opt, const std::vector<unsigned> &hist, bwahip_pestat_t pes[4])
+{
+	const int W = opt->max_ins + 1;
+	uint64_t cnt[4] = { 0, 0, 0, 0 };
+	memset(pes, 0, 4 * sizeof(bwahip_pestat_t));
+	for (int d = 0; d < 4; ++d) for (int v = 1; v < W; ++v) cnt[d] += hist[(size_t)d * W + v];
+	for (int d = 0; d < 4; ++d) {
+		bwahip_pestat_t *r = &pes[d];
+		const unsigned *h = &hist[(size_t)d * W];
+		const uint64_t nq = cnt[d];
+		if (nq < 10) { r->failed = 1; continue; }                    // MIN_DIR_CNT
+		auto at = [&](uint64_t idx) { uint64_t run = 0; for (int v = 1; v < W; ++v) { run += h[v]; if (run > idx) return v; } return W - 1; };
+		const int p25 = at((uint64_t)(int)(.25 * nq + .499)), p75 = at((uint64_t)(int)(.75 * nq + .499));
+		r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);              // OUTLIER_BOUND
+		if (r->low < 1) r->low = 1;
+		r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+		uint64_t x = 0;
+		r->avg = 0;
+		for (int v = 1; v < W; ++v) if (v >= r->low && v <= r->high) { r->avg += (double)v * h[v]; x += h[v]; }   // integers: exact in any order
+		r->avg /= x;
+		r->std = 0;
+		for (int v = 1; v < W; ++v) if (v >= r->low && v <= r->high) { const double t = ((double)v - r->avg) * ((double)v - r->avg); for (unsigned k = 0; k < h[v]; ++k) r->std += t; }
+		r->std = sqrt(r->std / x);
+		r->low = (int)(p25 - 3.0 * (p75 - p25) + .499);              // MAPPING_BOUND
+		r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+		if (r->low > r->avg - 4.0 * r->std) r->low = (int)(r->avg - 4.0 * r->std + .499);      // MAX_STDDEV
+		if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+		if (r->low < 1) r->low = 1;
+	}
+	uint64_t mx = 0;
+	for (int d = 0; d < 4; ++d) mx = mx > cnt[d] ? mx : cnt[d];
+	for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && cnt[d] < (int)mx * 0.05) pes[d].failed = 1;   // MIN_DIR_RATIO
+}
+
+// The paired-end stages before mark-primary: insert-size statistics, mate rescue.  Leaves the per-read lists in d_pe_regs.
+static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &dopt, int64_t n_processed, const bwahip_pestat_t *pes0, PairLaunch &pl)
 {
 	const int n = c->n_reads;
+	int rc;
+	memset(&pl, 0, sizeof pl);
+	pl.ix = c->ix; pl.opt = dopt; pl.n_reads = n; pl.seq = c->d_seq.as<uint8_t>(); pl.off = c->d_off.as<int64_t>(); pl.n_processed = n_processed;
+	pl.logtab = c->d_logtab.as<double>();
+	pl.regs = c->d_regs.as<DevReg>(); pl.reg_base = c->d_reg_base.as<int64_t>(); pl.reg_n = c->d_reg_n.as<int>();
+	unsigned long long *fm = c->d_fmisc.as<unsigned long long>();
+	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5;
+	bwahip_pestat_t pes[4];
+	if (pes0) memcpy(pes, pes0, sizeof pes);
+	else {
+		if (opt->max_ins < 1 || opt->max_ins > (1 << 24)) return BWAHIP_EINVAL;
+		const size_t hb = (size_t)4 * (opt->max_ins + 1) * 4;
+		if ((rc = c->d_hist.ensure(hb))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_hist.p, 0, hb, c->stream));
+		pl.hist = c->d_hist.as<unsigned>();
+		if ((rc = launch_pestat(pl, c->stream))) return rc;
+		std::vector<unsigned> h((size_t)4 * (opt->max_ins + 1));
+		HIP_TRY(hipMemcpyAsync(h.data(), c->d_hist.p, hb, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		pestat_from_hist(opt, h, pes);
+	}
+	memcpy(c->last_pes, pes, sizeof pes);
+	// per direction: .721 * log(2 * erfc(|ns| / sqrt 2)) for every admissible distance (bwamem_pair.c:243-244), by the host's libm
+	std::vector<double> tab;
+	int64_t widest = 0;
+	for (int d = 0; d < 4; ++d) {
+		pl.pes[d].low = pes[d].low; pl.pes[d].high = pes[d].high; pl.pes[d].failed = pes[d].failed; pl.pes[d].pad = 0; pl.pes[d].avg = pes[d].avg; pl.pes[d].std = pes[d].std;
+		pl.tab_off[d] = (int)tab.size();
+		if (pes[d].failed || pes[d].high < pes[d].low) continue;
+		if ((int64_t)pes[d].high - pes[d].low > (1 << 26)) return BWAHIP_EINVAL;
+		widest = std::max<int64_t>(widest, (int64_t)pes[d].high - pes[d].low);
+		for (int64_t dist = pes[d].low; dist <= pes[d].high; ++dist) {
+			const double ns = (dist - pes[d].avg) / pes[d].std;
+			tab.push_back(.721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)));
+		}
+	}
+	tab.push_back(0.);
+	if ((rc = dev_upload(c->d_pair_tab, tab.data(), tab.size() * 8, c->stream))) return rc;
+	pl.pair_tab = c->d_pair_tab.as<double>();
+	// list capacities after rescue
+	if ((rc = c->d_nb.ensure((size_t)n * 4)) || (rc = c->d_pe_cap.ensure((size_t)n * 4)) || (rc = c->d_pe_base.ensure((size_t)(n + 1) * 8)) || (rc = c->d_pe_n.ensure((size_t)n * 4)) ||
+	    (rc = c->d_resc.ensure((size_t)(n / 2 + 4) * 4))) return rc;
+	pl.nb = c->d_nb.as<int>(); pl.pe_cap = c->d_pe_cap.as<int>(); pl.pe_base = c->d_pe_base.as<int64_t>(); pl.pe_n = c->d_pe_n.as<int>(); pl.resc_list = c->d_resc.as<int>();
+	if ((rc = launch_pe_prepare(pl, c->stream))) return rc;
+	if ((rc = launch_scan(pl.pe_cap, c->d_pe_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
+	int64_t cap = 0;
+	HIP_TRY(hipMemcpyAsync(&cap, c->d_pe_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	const size_t R = (size_t)(cap ? cap : 1);
+	c->total_regs = cap;                                          // from here on the region slots are the paired-end ones
+	if ((rc = c->d_pe_regs.ensure(R * sizeof(DevReg))) || (rc = c->d_pe_tmp.ensure(R * sizeof(DevReg))) || (rc = c->d_pe_keys.ensure(R * 16)) || (rc = c->d_pe_idx.ensure(R * 8))) return rc;
+	pl.pe_regs = c->d_pe_regs.as<DevReg>(); pl.pe_tmp = c->d_pe_tmp.as<DevReg>(); pl.pe_keys = c->d_pe_keys.p; pl.pe_idx = c->d_pe_idx.as<int>();
+	if ((rc = launch_pe_copy(pl, c->stream))) return rc;
+	int n_resc = 0;
+	HIP_TRY(hipMemcpyAsync(&n_resc, pl.resc_n, 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (n_resc > 0) {
+		const int grid = std::min(n_resc, 2048);
+		pl.slab_stride = (matesw_slab_bytes(widest + c->max_len) + 255) & ~(size_t)255;
+		if ((rc = c->d_ms_slab.ensure(pl.slab_stride * (size_t)grid))) return rc;
+		pl.slab = c->d_ms_slab.as<uint8_t>();
+		if ((rc = launch_matesw(pl, grid, c->stream))) return rc;
+	}
+	HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 16, hipMemcpyDeviceToHost, c->stream));
+	return 0;
+}
+
+// K6 -> K9 over the batch run_pipeline left in HBM.  The text inputs (d_qual, d_names, ...) must be uploaded.
+int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const bwahip_pestat_t *pes0, bool timed)
+{
+	const int n = c->n_reads;
+	const bool pe = (opt->flag & BWAHIP_F_PE) != 0;
 	c->total_sam = 0; c->total_tasks = 0;
 	if (n == 0) return 0;
-	const size_t R = (size_t)(c->total_regs ? c->total_regs : 1);
+	if (pe && (n & 1)) return BWAHIP_EINVAL;
 	int rc;
+	HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 64, c->stream));
+	if (timed) HIP_TRY(hipEventRecord(c->ev[20], c->stream));
+	PairLaunch pl;
+	const DevOpt dopt_pe = make_dev_opt(opt);
+	if (pe && (rc = run_pe_rescue(c, opt, dopt_pe, n_processed, pes0, pl))) return rc;
+	const size_t R = (size_t)(c->total_regs ? c->total_regs : 1);
 	if ((rc = c->d_fregs.ensure(R * sizeof(FinReg))) || (rc = c->d_fregs2.ensure(R * sizeof(FinReg))) || (rc = c->d_fscr.ensure(R * 16)) || (rc = c->d_need.ensure(R)) ||
 	    (rc = c->d_xa_owner.ensure(R * 4)) || (rc = c->d_aln_of_reg.ensure(R * 4)) || (rc = c->d_rec_list.ensure(R * 8)) || (rc = c->d_xa_list.ensure(R * 8)) ||
 	    (rc = c->d_freg_n.ensure((size_t)n * 4)) || (rc = c->d_npri.ensure((size_t)n * 4)) || (rc = c->d_task_n.ensure((size_t)n * 4)) || (rc = c->d_rec_n.ensure((size_t)n * 4)) ||
@@ -50,6 +166,7 @@ int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bo
 	f.ix = c->ix; f.opt = make_dev_opt(opt); f.n_reads = n; f.seq = c->d_seq.as<uint8_t>(); f.off = c->d_off.as<int64_t>();
 	f.n_processed = n_processed; f.logtab = c->d_logtab.as<double>();
 	f.regs = c->d_regs.as<DevReg>(); f.reg_base = c->d_reg_base.as<int64_t>(); f.reg_n = c->d_reg_n.as<int>();
+	if (pe) { f.regs = c->d_pe_regs.as<DevReg>(); f.reg_base = c->d_pe_base.as<int64_t>(); f.reg_n = c->d_pe_n.as<int>(); }
 	f.fregs = c->d_fregs.as<FinReg>(); f.fregs2 = c->d_fregs2.as<FinReg>(); f.freg_n = c->d_freg_n.as<int>(); f.n_pri = c->d_npri.as<int>(); f.scr = c->d_fscr.as<int>();
 	f.need = c->d_need.as<uint8_t>(); f.xa_owner = c->d_xa_owner.as<int>(); f.task_n = c->d_task_n.as<int>(); f.rec_n = c->d_rec_n.as<int>();
 	f.task_base = c->d_task_base.as<int64_t>(); f.aln_of_reg = c->d_aln_of_reg.as<int>();
@@ -61,9 +178,16 @@ int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bo
 	f.ctg_names = c->d_ctg_names.as<uint8_t>(); f.ctg_name_off = c->d_ctg_name_off.as<int>(); f.ctg_anno = c->d_ctg_anno.as<uint8_t>(); f.ctg_anno_off = c->d_ctg_anno_off.as<int>();
 	f.rg_id = c->d_rg.as<uint8_t>(); f.rg_len = (int)c->rg_id.size();
 	f.sam_len = c->d_sam_len.as<int>(); f.sam_off = c->d_sam_off.as<int64_t>();
-	HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 64, c->stream));
 	if (timed) HIP_TRY(hipEventRecord(c->ev[15], c->stream));
-	if ((rc = launch_mark_primary(f, true, c->stream))) return rc;
+	if ((rc = launch_mark_primary(f, !pe, c->stream))) return rc;
+	if (pe) {                                                     // mem_pair + the decisions of mem_sam_pe
+		if ((rc = c->d_pe_read.ensure((size_t)n * sizeof(PeRead)))) return rc;
+		pl.fregs = f.fregs; pl.fregs_w = f.fregs; pl.freg_n = f.freg_n; pl.n_pri = f.n_pri; pl.need = f.need; pl.xa_owner = f.xa_owner;
+		pl.task_n = f.task_n; pl.rec_n = f.rec_n; pl.scr = f.scr; pl.pe_read = c->d_pe_read.as<PeRead>();
+		if ((rc = launch_pair(pl, c->stream))) return rc;
+		f.pe_read = pl.pe_read;
+		memcpy(f.pes, pl.pes, sizeof f.pes);
+	}
 	if ((rc = launch_scan(c->d_task_n.as<int>(), c->d_task_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 	if (timed) HIP_TRY(hipEventRecord(c->ev[16], c->stream));
 	int64_t T = 0;
@@ -103,7 +227,7 @@ int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bo
 		break;
 	}
 	if (timed) HIP_TRY(hipEventRecord(c->ev[17], c->stream));
-	if ((rc = launch_sam(f, false, c->stream))) return rc;
+	if ((rc = pe ? launch_sam_pe(f, false, c->stream) : launch_sam(f, false, c->stream))) return rc;
 	if ((rc = launch_scan(c->d_sam_len.as<int>(), c->d_sam_off.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 	if (timed) HIP_TRY(hipEventRecord(c->ev[18], c->stream));
 	int64_t total = 0;
@@ -112,7 +236,7 @@ int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bo
 	c->total_sam = total;
 	if ((rc = c->d_sam.ensure((size_t)total + 64))) return rc;
 	f.sam = c->d_sam.as<uint8_t>();
-	if ((rc = launch_sam(f, true, c->stream))) return rc;
+	if ((rc = pe ? launch_sam_pe(f, true, c->stream) : launch_sam(f, true, c->stream))) return rc;
 	if (timed) {
 		HIP_TRY(hipEventRecord(c->ev[19], c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -120,6 +244,7 @@ int run_final_se(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, bo
 		HIP_TRY(hipEventElapsedTime(&c->final_ms[1], c->ev[16], c->ev[17]));
 		HIP_TRY(hipEventElapsedTime(&c->final_ms[2], c->ev[17], c->ev[18]));
 		HIP_TRY(hipEventElapsedTime(&c->final_ms[3], c->ev[18], c->ev[19]));
+		HIP_TRY(hipEventElapsedTime(&c->final_ms[4], c->ev[20], c->ev[15]));   // paired-end: insert sizes + mate rescue
 	}
 	return 0;
 }
@@ -176,13 +301,14 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	if (!ctx || !opt || n < 0 || (n && !seqs)) return BWAHIP_EINVAL;
 	const bool pe = (opt->flag & BWAHIP_F_PE) != 0;
 	if (pe && (n & 1)) return BWAHIP_EINVAL;
-	if (pe || !ctx->knobs.gpu_final) return bwahip_process_seqs_host(ctx, opt, n_processed, n, seqs, pes0);
+	if (!ctx->knobs.gpu_final || (pe && !ctx->knobs.gpu_pair)) return bwahip_process_seqs_host(ctx, opt, n_processed, n, seqs, pes0);
+	if (pe) for (int i = 0; i < n; i += 2) if (strcmp(seqs[i].name, seqs[i + 1].name) != 0) { fprintf(stderr, "[bwahip] paired reads have different names\n"); return BWAHIP_EINVAL; }   // err_fatal in the reference (bwamem_pair.c:386)
 	if (n == 0) return 0;
 	HIP_TRY(hipSetDevice(ctx->device));
 	int rc = upload_batch_text(ctx, opt->n_threads, n, seqs);
 	if (rc) return rc;
 	if ((rc = run_pipeline(ctx, opt, false, false))) return rc;
-	if ((rc = run_final_se(ctx, opt, n_processed, false))) return rc;
+	if ((rc = run_final(ctx, opt, n_processed, pes0, false))) return rc;
 	// SAM text back in one piece, then one malloc()ed string per read as the reference's contract wants (bwamem.c:1054)
 	std::vector<int64_t> soff(n + 1);
 	std::vector<char> text((size_t)ctx->total_sam + 1);
@@ -201,4 +327,16 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 		}
 	});
 	return oom ? BWAHIP_ENOMEM : 0;
+}
+
+// Insert-size statistics (mem_pestat_t x 4: FF, FR, RF, RR) and mate-rescue counters ([0] Smith-Waterman alignments run on
+// the GPU, [1] regions they added) of the last paired-end batch bwahip_process_seqs finalised on the GPU.
+extern "C" int bwahip_last_pe_stats(bwahip_ctx *ctx, bwahip_pestat_t *pes4, uint64_t *counters2)
+{
+	if (!ctx) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if (pes4) memcpy(pes4, ctx->last_pes, sizeof ctx->last_pes);
+	if (counters2) { counters2[0] = ctx->last_pe_counters[0]; counters2[1] = ctx->last_pe_counters[1]; }
+	return 0;
 }

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 			if ((P == 16) != (l_ms * a.opt.a < 250)) continue;    // the other instantiation takes this mate length
 			DevReg *L = a.pe_regs + a.pe_base[rm];
 			DevReg *tmp = a.pe_tmp + a.pe_base[rm];
-			RegKey *keys = a.pe_keys + a.pe_base[rm];
+			RegKey *keys = reinterpret_cast<RegKey*>(a.pe_keys) + a.pe_base[rm];
 			int *idx = a.pe_idx + 2 * a.pe_base[rm];
 			const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk };
 			const DevReg *snap = a.regs + a.reg_base[r];            // b[i]: the end's own regions as mem_align1_core left them
@@ -559,9 +559,9 @@ __global__ __launch_bounds__(64) void k_pair(PairLaunch a)
 
 } // namespace
 
-size_t matesw_slab_bytes(int max_ins, int max_len)
+size_t matesw_slab_bytes(int64_t window)                            // window: the widest reference window (high - low + mate length)
 {
-	const size_t win = (size_t)max_ins + 2 * (size_t)max_len + 256;     // the widest reference window: high - low + l_ms
+	const size_t win = (size_t)window + 256;
 	return ((win + 63) / 64 * 64) + win * 2 + 256;                      // + one 16-bit column maximum per window base
 }
 

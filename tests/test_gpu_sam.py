@@ -73,6 +73,43 @@ def test_pe_sam_identical(ctx, small_index, tmp_path, name, n, length, sub, inde
     assert got == want, _first_diff(got, want)
 
 
+def test_pe_stages_ran_on_the_gpu_and_match_host_finalisation(ctx, small_index, tmp_path):
+    """The paired-end path end to end on the GPU (insert-size histogram, mate rescue with the lane-exact striped SW,
+    mem_pair, paired SAM): mate-rescue alignments really ran there, the statistics are the reference's, and the SAM is
+    the same whether finalisation runs on the GPU or (knobs gpu_final / gpu_pair = 0) on host threads."""
+    fq1, fq2 = str(tmp_path / "x_1.fq"), str(tmp_path / "x_2.fq")
+    bw.make_reads(small_index["fa"], fq1, fq2, 5000, 150, 40000, 4000, 2000, 233)
+    n1, s1, q1 = bw.read_fastq(fq1)
+    n2, s2, q2 = bw.read_fastq(fq2)
+    names = [x for p in zip(n1, n2) for x in p]
+    seqs = [x for p in zip(s1, s2) for x in p]
+    quals = [x for p in zip(q1, q2) for x in p]
+    r = subprocess.run([common.ORACLE, "mem", "-t", "8", small_index["prefix"], fq1, fq2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    opt = bw.default_opt()
+    opt.n_threads = 8
+    opt.flag |= 0x2
+    got = b"".join(ctx.process_seqs(names, seqs, quals, opt))
+    assert got == r.stdout, _first_diff(got, r.stdout)
+    pes, n_sw, n_new = ctx.last_pe_stats()
+    assert n_sw > 50 and n_new > 10, (n_sw, n_new)                       # 4 % substitutions: many mates need rescue
+    assert pes[1]["failed"] == 0 and 450 < pes[1]["avg"] < 550 and pes[0]["failed"] == pes[2]["failed"] == pes[3]["failed"] == 1
+    try:
+        ctx.tune(gpu_pair=0)
+        host = b"".join(ctx.process_seqs(names, seqs, quals, opt))
+    finally:
+        ctx.tune(gpu_pair=1)
+    assert host == got
+    # single-end: GPU finalisation vs host finalisation
+    opt.flag &= ~0x2
+    a = b"".join(ctx.process_seqs(n1, s1, q1, opt))
+    try:
+        ctx.tune(gpu_final=0)
+        b = b"".join(ctx.process_seqs(n1, s1, q1, opt))
+    finally:
+        ctx.tune(gpu_final=1)
+    assert a == b
+
+
 def _first_diff(got, want):
     g, w = got.split(b"\n"), want.split(b"\n")
     for i, (a, b) in enumerate(zip(g, w)):
