@@ -100,6 +100,9 @@ def lib():
     L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
     L.bwahip_batch_upload.argtypes = [vp, C.c_int, vp, vp]
     L.bwahip_batch_attach.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int64]
+    L.bwahip_batch_attach_text.argtypes = [vp, vp, vp, vp, vp]
+    L.bwahip_batch_run_sam.argtypes = [vp, C.POINTER(Opt), C.c_int64, C.POINTER(PeStat), C.POINTER(C.c_float), C.c_int]
+    L.bwahip_batch_sam.argtypes = [vp, C.POINTER(vp), i64p, vp]
     L.bwahip_batch_run.argtypes = [vp, C.POINTER(Opt), C.POINTER(C.c_float), C.c_int]
     L.bwahip_batch_counters.argtypes = [vp, u64p, C.c_int]
     L.bwahip_kernel_name.restype = C.c_char_p
@@ -255,6 +258,26 @@ class Context:
         """Use reads already resident in HBM (device pointers); nothing is copied."""
         _check(lib().bwahip_batch_attach(self._h, n, seq_ptr, off_ptr, max_len, total_bases), "bwahip_batch_attach")
 
+    def batch_attach_text(self, qual_ptr, qual_off_ptr, names_ptr, name_off_ptr):
+        _check(lib().bwahip_batch_attach_text(self._h, qual_ptr, qual_off_ptr, names_ptr, name_off_ptr), "bwahip_batch_attach_text")
+
+    def batch_run_sam(self, opt=None, n_processed=0, pes0=None):
+        """Hot path + finalisation + SAM text, all on the GPU, over the attached batch; returns per-stage milliseconds."""
+        opt = opt or default_opt()
+        nk = lib().bwahip_n_kernels()
+        ms = (C.c_float * nk)()
+        _check(lib().bwahip_batch_run_sam(self._h, C.byref(opt), n_processed, pes0, ms, nk), "bwahip_batch_run_sam")
+        return {lib().bwahip_kernel_name(i).decode(): float(ms[i]) for i in range(nk)}
+
+    def batch_sam(self):
+        out, ln = C.c_void_p(), C.c_int64()
+        _check(lib().bwahip_batch_sam(self._h, C.byref(out), C.byref(ln), None), "bwahip_batch_sam")
+        sam = C.string_at(out, ln.value)
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(out)
+        return sam
+
     def batch_run(self, opt=None):
         opt = opt or default_opt()
         nk = lib().bwahip_n_kernels()
@@ -265,11 +288,12 @@ class Context:
     @staticmethod
     def stage_names():
         return ["k_smem(passes 1-2)+k_smem_heavy+k_smem3(pass 3)+k_intv_sort", "k_seeds", "k_chain(+k_chain_big,k_chain_flt)", "k_seed_sw (only with -W / reads > 700 bp)",
-                "k_extend_spec+k_extend(+k_extend_big, dedup/patch)"]
+                "k_extend_spec+k_extend(+k_extend_big, dedup/patch)", "PE: k_pestat+k_matesw (insert sizes, mate rescue)", "k_mark (mark primary) + PE: k_pair (pairing)",
+                "k_cigar (mem_reg2aln: mapQ, CIGAR by ksw_global2 backtrack, NM/MD)", "k_sam size + scan + write (SAM text)"]
 
     @staticmethod
     def output_description(paired):
-        return "mem_alnreg_v per read resident in HBM (== mem_align1_core for every read" + (" of every pair)" if paired else ")")
+        return "SAM text of the batch in HBM (== seqs[i].sam of mem_process_seqs, " + ("paired-end: mate rescue, pairing, paired records)" if paired else "single-end)")
 
     def counters(self):
         buf = (C.c_uint64 * 32)()

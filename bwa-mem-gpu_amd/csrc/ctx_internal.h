@@ -23,6 +23,22 @@ struct DevBuf {
 };
 
 
+// pinned host staging buffer (grows, never shrinks)
+struct HostBuf {
+	void *p = nullptr; size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap) return 0;
+		if (p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		const size_t want = bytes + bytes / 8 + 4096;
+		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "[bwahip] hipHostMalloc(%zu) failed\n", want); p = nullptr; return BWAHIP_ENOMEM; }
+		cap = want;
+		return 0;
+	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // Tuning knobs (hand-off thresholds of the heavy-read kernels).  Read from the environment ONCE, when the context is
 // created; bwahip_ctx_tune changes them afterwards (tests force every hand-off kernel onto ordinary reads that way).
 struct Knobs {
@@ -77,6 +93,7 @@ struct bwahip_ctx {
 	bwahip_pestat_t last_pes[4];         // insert-size statistics of the last paired-end batch
 	unsigned long long last_pe_counters[2] = { 0, 0 };   // mate-rescue alignments run / regions added
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
+	HostBuf h_stage, h_sam;               // pinned staging: batch text in, SAM text out
 	int64_t total_tasks = 0, total_sam = 0;
 	size_t pool_cap = 0;
 	float final_ms[8] = { 0 };           // k_mark, k_cigar, k_sam(size), k_sam(write) of the last run

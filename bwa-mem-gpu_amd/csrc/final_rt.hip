@@ -6,6 +6,7 @@
 #include <thread>
 #include <math.h>
 #include <algorithm>
+#include <chrono>
 
 int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);   // host_final.cpp
 
@@ -275,7 +276,15 @@ static int upload_batch_text(bwahip_ctx *c, int nt, int n, bwahip_seq_t *seqs)
 		coff[i + 1] = coff[i] + (lc ? lc + 1 : 0);
 		any_comment |= lc > 0;
 	}
-	std::vector<uint8_t> codes((size_t)off[n] + 1), qual((size_t)qtot + 64), names((size_t)noff[n] + 64, 0), comments(any_comment ? (size_t)coff[n] + 64 : 0, 0);
+	// one pinned staging buffer (kept by the context) holds codes | qualities | names | comments: the copies to HBM then run at
+	// PCIe speed instead of through pageable memory
+	const size_t sz_codes = ((size_t)off[n] + 64) & ~(size_t)63, sz_qual = ((size_t)qtot + 127) & ~(size_t)63, sz_names = ((size_t)noff[n] + 127) & ~(size_t)63,
+	             sz_comm = any_comment ? ((size_t)coff[n] + 127) & ~(size_t)63 : 0;
+	int rc = c->h_stage.ensure(sz_codes + sz_qual + sz_names + sz_comm);
+	if (rc) return rc;
+	uint8_t *codes = (uint8_t*)c->h_stage.p, *qual = codes + sz_codes, *names = qual + sz_qual, *comments = names + sz_names;
+	memset(qual + (size_t)qtot, 0, sz_qual - (size_t)qtot); memset(names + (size_t)noff[n], 0, sz_names - (size_t)noff[n]);
+	if (any_comment) memset(comments + (size_t)coff[n], 0, sz_comm - (size_t)coff[n]);
 	par_for_chunks(n, nt, [&](int64_t b, int64_t e) {
 		for (int64_t i = b; i < e; ++i) {
 			char *s = seqs[i].seq;
@@ -285,12 +294,12 @@ static int upload_batch_text(bwahip_ctx *c, int nt, int n, bwahip_seq_t *seqs)
 			if (any_comment && coff[i + 1] > coff[i]) memcpy(&comments[coff[i]], seqs[i].comment, coff[i + 1] - coff[i]);
 		}
 	});
-	int rc = bwahip_batch_upload(c, n, codes.data(), off.data());
+	rc = bwahip_batch_upload(c, n, codes, off.data());
 	if (rc) return rc;
-	if ((rc = dev_upload(c->d_qual, qual.data(), qual.size(), c->stream)) || (rc = dev_upload(c->d_qual_off, qoff.data(), (size_t)n * 8, c->stream)) ||
-	    (rc = dev_upload(c->d_names, names.data(), names.size(), c->stream)) || (rc = dev_upload(c->d_name_off, noff.data(), (size_t)(n + 1) * 8, c->stream)) ||
+	if ((rc = dev_upload(c->d_qual, qual, sz_qual, c->stream)) || (rc = dev_upload(c->d_qual_off, qoff.data(), (size_t)n * 8, c->stream)) ||
+	    (rc = dev_upload(c->d_names, names, sz_names, c->stream)) || (rc = dev_upload(c->d_name_off, noff.data(), (size_t)(n + 1) * 8, c->stream)) ||
 	    (rc = dev_upload(c->d_comment_off, coff.data(), (size_t)(n + 1) * 8, c->stream))) return rc;
-	if (any_comment) { if ((rc = dev_upload(c->d_comments, comments.data(), comments.size(), c->stream))) return rc; }
+	if (any_comment) { if ((rc = dev_upload(c->d_comments, comments, sz_comm, c->stream))) return rc; }
 	else c->d_comments.release();
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return 0;
@@ -305,27 +314,36 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	if (pe) for (int i = 0; i < n; i += 2) if (strcmp(seqs[i].name, seqs[i + 1].name) != 0) { fprintf(stderr, "[bwahip] paired reads have different names\n"); return BWAHIP_EINVAL; }   // err_fatal in the reference (bwamem_pair.c:386)
 	if (n == 0) return 0;
 	HIP_TRY(hipSetDevice(ctx->device));
+	const bool verbose = ctx->knobs.verbose != 0;
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
 	int rc = upload_batch_text(ctx, opt->n_threads, n, seqs);
 	if (rc) return rc;
+	const double t1 = now();
 	if ((rc = run_pipeline(ctx, opt, false, false))) return rc;
+	const double t2 = now();
 	if ((rc = run_final(ctx, opt, n_processed, pes0, false))) return rc;
-	// SAM text back in one piece, then one malloc()ed string per read as the reference's contract wants (bwamem.c:1054)
+	// SAM text back in one piece (pinned staging buffer, on the context's stream: it is a non-blocking stream, a plain hipMemcpy
+	// would not wait for the SAM kernel), then one malloc()ed string per read as the reference's contract wants (bwamem.c:1054)
 	std::vector<int64_t> soff(n + 1);
-	std::vector<char> text((size_t)ctx->total_sam + 1);
-	// (on the context's stream: it is a non-blocking stream, a plain hipMemcpy would not wait for the SAM kernel)
+	if ((rc = ctx->h_sam.ensure((size_t)ctx->total_sam + 1))) return rc;
+	char *text = (char*)ctx->h_sam.p;
 	HIP_TRY(hipMemcpyAsync(soff.data(), ctx->d_sam_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-	if (ctx->total_sam) HIP_TRY(hipMemcpyAsync(text.data(), ctx->d_sam.p, (size_t)ctx->total_sam, hipMemcpyDeviceToHost, ctx->stream));
+	if (ctx->total_sam) HIP_TRY(hipMemcpyAsync(text, ctx->d_sam.p, (size_t)ctx->total_sam, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	const double t3 = now();
 	std::atomic<int> oom(0);
 	par_for_chunks(n, opt->n_threads, [&](int64_t b, int64_t e) {
 		for (int64_t i = b; i < e; ++i) {
 			const size_t len = (size_t)(soff[i + 1] - soff[i]);
 			char *p = (char*)malloc(len + 1);
 			if (!p) { oom = 1; seqs[i].sam = nullptr; continue; }
-			memcpy(p, text.data() + soff[i], len); p[len] = 0;
+			memcpy(p, text + soff[i], len); p[len] = 0;
 			seqs[i].sam = p;
 		}
 	});
+	if (verbose) fprintf(stderr, "[bwahip] process_seqs %d reads: gather+upload %.1f ms, hot path %.1f ms, finalisation+SAM on GPU+download %.1f ms (%lld bytes), per-read strings %.1f ms\n",
+	                     n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)ctx->total_sam, (now() - t3) * 1e3);
 	return oom ? BWAHIP_ENOMEM : 0;
 }
 

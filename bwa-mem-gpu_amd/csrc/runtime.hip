@@ -80,7 +80,8 @@ int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st)
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
-static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec", "k_smem3", "k_intv_sort", "k_seed_sw" };
+static const char *g_kernel_names[] = { "k_smem", "k_scan", "k_seeds", "k_chain", "k_scan2", "k_extend", "k_smem_heavy", "k_extend_spec", "k_smem3", "k_intv_sort", "k_seed_sw",
+                                         "pe_rescue", "k_mark", "k_cigar", "k_sam_size", "k_sam_write" };   // [11..15]: finalisation stages (bwahip_batch_run_sam)
 
 DevOpt make_dev_opt(const bwahip_opt_t *o)
 {
@@ -263,6 +264,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_hist, &c->d_pair_tab, &c->d_nb, &c->d_pe_cap, &c->d_pe_base, &c->d_pe_regs, &c->d_pe_n, &c->d_pe_tmp, &c->d_pe_keys, &c->d_pe_idx, &c->d_resc, &c->d_ms_slab, &c->d_pe_read };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
+	c->h_stage.release(); c->h_sam.release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -614,6 +616,54 @@ int bwahip_batch_run(bwahip_ctx *c, const bwahip_opt_t *opt, float *kernel_ms, i
 	int rc = run_pipeline(c, opt, true, false);
 	if (!rc && kernel_ms) for (int i = 0; i < n_ms && i < bwahip_n_kernels(); ++i) kernel_ms[i] = c->last_ms[i];
 	return rc;
+}
+
+// The text the SAM stage prints for the attached batch, already in HBM: qualities (read r at qual_dev + qual_off_dev[r], < 0: none),
+// NUL-terminated names (read r at names_dev + name_off_dev[r]; the buffer must extend 64 bytes past the last name).
+int bwahip_batch_attach_text(bwahip_ctx *c, const uint8_t *qual_dev, const int64_t *qual_off_dev, const uint8_t *names_dev, const int64_t *name_off_dev)
+{
+	if (!c || !names_dev || !name_off_dev || (qual_dev && !qual_off_dev)) return BWAHIP_EINVAL;
+	const int n = c->n_reads;
+	c->d_qual.adopt((void*)qual_dev, 0); c->d_qual_off.adopt((void*)qual_off_dev, (size_t)n * 8);
+	c->d_names.adopt((void*)names_dev, 0); c->d_name_off.adopt((void*)name_off_dev, (size_t)(n + 1) * 8);
+	c->d_comments.release();
+	int rc = c->d_comment_off.ensure((size_t)(n + 1) * 8);
+	if (rc) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMemsetAsync(c->d_comment_off.p, 0, (size_t)(n + 1) * 8, c->stream));
+	return 0;
+}
+
+// mem_process_seqs over the attached batch, everything on the GPU: hot path, then finalisation and SAM text, which stays in HBM
+// (bwahip_batch_sam downloads it).  kernel_ms as bwahip_batch_run, entries 11..15 = the finalisation stages.
+int bwahip_batch_run_sam(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const bwahip_pestat_t *pes0, float *kernel_ms, int n_ms)
+{
+	if (!c || !opt) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = run_pipeline(c, opt, true, false);
+	if (!rc) rc = run_final(c, opt, n_processed, pes0, true);
+	if (!rc && kernel_ms) {
+		for (int i = 0; i < n_ms && i < 11; ++i) kernel_ms[i] = c->last_ms[i];
+		if (n_ms > 11) kernel_ms[11] = c->final_ms[4];
+		for (int i = 0; i < 4 && 12 + i < n_ms; ++i) kernel_ms[12 + i] = c->final_ms[i];
+	}
+	return rc;
+}
+
+// SAM text of the last bwahip_batch_run_sam: *out = malloc()ed buffer of *out_len bytes (reads in order); off (may be NULL):
+// n + 1 offsets of the reads' texts
+int bwahip_batch_sam(bwahip_ctx *c, char **out, int64_t *out_len, int64_t *off)
+{
+	if (!c || !out || !out_len) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	char *buf = (char*)malloc((size_t)c->total_sam + 1);
+	if (!buf) return BWAHIP_ENOMEM;
+	if (c->total_sam) HIP_TRY(hipMemcpyAsync(buf, c->d_sam.p, (size_t)c->total_sam, hipMemcpyDeviceToHost, c->stream));
+	if (off && c->n_reads) HIP_TRY(hipMemcpyAsync(off, c->d_sam_off.p, (size_t)(c->n_reads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	buf[c->total_sam] = 0;
+	*out = buf; *out_len = c->total_sam;
+	return 0;
 }
 
 int bwahip_batch_counters(bwahip_ctx *c, uint64_t *counters, int n)

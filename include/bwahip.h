@@ -224,6 +224,14 @@ int bwahip_batch_upload(bwahip_ctx *ctx, int n, const uint8_t *seq, const int64_
 int bwahip_batch_attach(bwahip_ctx *ctx, int n, const uint8_t *seq_dev, const int64_t *off_dev, int max_len, int64_t total_bases);
 int bwahip_batch_run(bwahip_ctx *ctx, const bwahip_opt_t *opt, float *kernel_ms, int n_kernel_ms);
 int bwahip_batch_download(bwahip_ctx *ctx, bwahip_alnreg_v *regs_out);       /* regs of the last run */
+/* The whole of mem_process_seqs on a device-resident batch: attach the text the SAM stage prints (qualities: read r at
+ * qual_dev + qual_off_dev[r], or qual_off_dev[r] < 0 / qual_dev NULL for none; NUL-terminated names at names_dev +
+ * name_off_dev[r], buffer padded by 64 bytes), run hot path + finalisation + SAM text on the GPU (SE, or PE when
+ * opt->flag has MEM_F_PE; n_processed / pes0 as in mem_process_seqs), then fetch the text.  kernel_ms: as
+ * bwahip_batch_run; entries 11..15 are the finalisation stages (see bwahip_kernel_name). */
+int bwahip_batch_attach_text(bwahip_ctx *ctx, const uint8_t *qual_dev, const int64_t *qual_off_dev, const uint8_t *names_dev, const int64_t *name_off_dev);
+int bwahip_batch_run_sam(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, const bwahip_pestat_t *pes0, float *kernel_ms, int n_kernel_ms);
+int bwahip_batch_sam(bwahip_ctx *ctx, char **out, int64_t *out_len, int64_t *off);
 int bwahip_n_kernels(void);
 const char *bwahip_kernel_name(int i);
 /* Algorithmic work counters of the last bwahip_batch_run, counted on the device by the kernels
