@@ -205,6 +205,9 @@ def main():
         if b == 0:
             sam_resident0 = ctx.batch_sam()
             sam_bytes = len(sam_resident0)
+            if pe:
+                pes_b0 = ctx.last_pe_stats()[0]
+                log(f"batch 0: insert size FR {pes_b0[1]}; mate rescue {ctx.pe_counters}")
     counters = {k: (max(c[k] for c in cnts) if k.endswith("_max") or k.startswith("max_") else sum(c[k] for c in cnts)) for k in cnts[0]}
 
     # ---------------- end to end (host buffers in -> SAM text out) on the first --cpu-sample reads, one mem_process_seqs batch

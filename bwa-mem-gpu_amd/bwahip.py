@@ -245,8 +245,9 @@ class Context:
     def last_pe_stats(self):
         """(pestat[4] as dicts, mate-rescue alignments run on the GPU, regions they added) of the last PE batch."""
         pes = (PeStat * 4)()
-        cnt = (C.c_uint64 * 2)()
+        cnt = (C.c_uint64 * 4)()
         _check(lib().bwahip_last_pe_stats(self._h, pes, cnt), "bwahip_last_pe_stats")
+        self.pe_counters = dict(sw=int(cnt[0]), added=int(cnt[1]), max_sw_per_pair=int(cnt[2]), pairs_rescued=int(cnt[3]))
         return [dict(low=p.low, high=p.high, failed=p.failed, avg=p.avg, std=p.std) for p in pes], int(cnt[0]), int(cnt[1])
 
     def batch_upload(self, codes, off):

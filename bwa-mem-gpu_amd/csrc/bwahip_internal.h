@@ -194,7 +194,9 @@ struct DevAln {
 	int32_t n_cigar, score, sub, alt_sc;
 	int64_t cigar_off;                           // byte offset of n_cigar uint32 words in the pool
 	int64_t md_off; int32_t md_len, pad;
+	int64_t pad2;                                // 80 bytes: elements of an array stay 16-byte aligned
 };
+static_assert(sizeof(DevAln) == 80 && sizeof(DevReg) == 80, "record sizes");
 // what a region is needed for (FinLaunch::need)
 enum { NEED_REC = 1 /* prints a SAM record */, NEED_XA = 2 /* listed in another record's XA tag */, NEED_H = 4 /* only as the mate information of the other end (h[i], bwamem_pair.c:404) */ };
 struct DevPes { int low, high, failed, pad; double avg, std; };   // mem_pestat_t, bwa.h:167-171

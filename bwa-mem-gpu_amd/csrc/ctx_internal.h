@@ -91,7 +91,7 @@ struct bwahip_ctx {
 	DevBuf d_fregs, d_fregs2, d_fscr, d_need, d_xa_owner, d_freg_n, d_npri, d_task_n, d_rec_n, d_task_base, d_tasks, d_aln_of_reg, d_alns;
 	DevBuf d_hist, d_pair_tab, d_nb, d_pe_cap, d_pe_base, d_pe_regs, d_pe_n, d_pe_tmp, d_pe_keys, d_pe_idx, d_resc, d_ms_slab, d_pe_read;   // paired-end stages
 	bwahip_pestat_t last_pes[4];         // insert-size statistics of the last paired-end batch
-	unsigned long long last_pe_counters[2] = { 0, 0 };   // mate-rescue alignments run / regions added
+	unsigned long long last_pe_counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // mate-rescue alignments run / regions added / most per pair / pairs rescued
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
 	HostBuf h_stage, h_sam;               // pinned staging: batch text in, SAM text out
 	int64_t total_tasks = 0, total_sam = 0;

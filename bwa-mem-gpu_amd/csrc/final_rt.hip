@@ -25,7 +25,7 @@ int final_setup(bwahip_ctx *c)
 	int rc;
 	if ((rc = dev_upload(c->d_ctg_names, names.data(), names.size(), c->stream)) || (rc = dev_upload(c->d_ctg_name_off, noff.data(), noff.size() * 4, c->stream)) ||
 	    (rc = dev_upload(c->d_ctg_anno, anno.data(), anno.size(), c->stream)) || (rc = dev_upload(c->d_ctg_anno_off, aoff.data(), aoff.size() * 4, c->stream)) ||
-	    (rc = c->d_fmisc.ensure(64))) return rc;
+	    (rc = c->d_fmisc.ensure(128))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return 0;
 }
@@ -133,7 +133,10 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 		pl.slab = c->d_ms_slab.as<uint8_t>();
 		if ((rc = launch_matesw(pl, grid, c->stream))) return rc;
 	}
-	HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 16, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 64, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->last_pe_counters[3] = (unsigned long long)n_resc;
+	if (c->knobs.verbose) fprintf(stderr, "[bwahip] mate rescue: %llu SW, %llu added, max %llu per pair, %d pairs; ticks(10ns) window %llu sw %llu dedup %llu, slowest pair %llu\n", c->last_pe_counters[0], c->last_pe_counters[1], c->last_pe_counters[2], n_resc, c->last_pe_counters[4], c->last_pe_counters[5], c->last_pe_counters[6], c->last_pe_counters[7]);
 	return 0;
 }
 
@@ -146,7 +149,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	if (n == 0) return 0;
 	if (pe && (n & 1)) return BWAHIP_EINVAL;
 	int rc;
-	HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 64, c->stream));
+	HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 128, c->stream));
 	if (timed) HIP_TRY(hipEventRecord(c->ev[20], c->stream));
 	PairLaunch pl;
 	const DevOpt dopt_pe = make_dev_opt(opt);
@@ -204,7 +207,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 		if ((rc = c->d_pool.ensure(want_pool))) return rc;
 		c->pool_cap = want_pool;
 		f.pool = c->d_pool.as<uint8_t>(); f.pool_cap = want_pool;
-		HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 64, c->stream));
+		HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 128, c->stream));
 		if ((rc = launch_cigar(f, T, c->stream))) return rc;
 		int h[6] = { 0 };
 		HIP_TRY(hipMemcpyAsync(h, c->d_fmisc.p, 24, hipMemcpyDeviceToHost, c->stream));
@@ -348,13 +351,14 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 }
 
 // Insert-size statistics (mem_pestat_t x 4: FF, FR, RF, RR) and mate-rescue counters ([0] Smith-Waterman alignments run on
-// the GPU, [1] regions they added) of the last paired-end batch bwahip_process_seqs finalised on the GPU.
+// the GPU, [1] regions they added, [2] most alignments of one pair, [3] pairs that needed any) of the last paired-end batch
+// finalised on the GPU.
 extern "C" int bwahip_last_pe_stats(bwahip_ctx *ctx, bwahip_pestat_t *pes4, uint64_t *counters2)
 {
 	if (!ctx) return BWAHIP_EINVAL;
 	HIP_TRY(hipSetDevice(ctx->device));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	if (pes4) memcpy(pes4, ctx->last_pes, sizeof ctx->last_pes);
-	if (counters2) { counters2[0] = ctx->last_pe_counters[0]; counters2[1] = ctx->last_pe_counters[1]; }
+	if (counters2) for (int i = 0; i < 4; ++i) counters2[i] = ctx->last_pe_counters[i];
 	return 0;
 }

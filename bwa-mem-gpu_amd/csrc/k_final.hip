@@ -306,7 +306,7 @@ struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; }
 // One task: region `ar` of read r -> DevAln (+ CIGAR words and MD text appended to the pool).  BIG: window / matrix in the
 // workgroup's global slab.  Returns false when the task does not fit this variant (caller lists it for k_cigar_big).
 template <bool BIG>
-__device__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, const CigarLds &m, int t_cap, size_t z_cap, DevAln *out)
+__device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, const CigarLds &m, int t_cap, size_t z_cap, DevAln *out)
 {
 	const int l = lane();
 	const DevOpt &opt = a.opt;
@@ -467,7 +467,7 @@ __device__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, const Cigar
 	al.pos = pos - ix.anns[al.rid].offset;
 	al.score = ar.score; al.sub = ar.sub > ar.csub ? ar.sub : ar.csub;
 	al.is_alt = (uint32_t)ar.is_alt; al.alt_sc = ar.alt_sc;
-	al.n_cigar = n_out; al.md_len = md_len; al.pad = 0;
+	al.n_cigar = n_out; al.md_len = md_len; al.pad = 0; al.pad2 = 0;
 	// ---- CIGAR words + MD text into the pool
 	const unsigned long long bytes = ((unsigned long long)n_out * 4 + (unsigned long long)md_len + 7) & ~7ull;
 	unsigned long long at = 0;

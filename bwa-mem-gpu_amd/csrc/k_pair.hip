@@ -125,18 +125,20 @@ __global__ void k_pe_copy(PairLaunch a)
 
 // ---------------------------------------------------------------------------------------------------- mem_matesw
 constexpr int MS_MAXQ = BWAHIP_MAX_READ_LEN;
-constexpr int MS_LIST = 128;                                 // regions of a list kept in LDS while it is re-sorted
+constexpr int MS_LIST = 96;                                  // regions of a mate list worked on in LDS
 
 struct MsLds {
 	uint8_t *q;                                                  // mate read (or its reverse complement), codes
 	int8_t *mat;
 	int8_t *prof; int16_t *h;                                    // striped-SW working set: 5 + 4 x 2 bytes per cell
-	RegKey *keys; int *idx; int *stk;                            // sort scratch (MS_LIST entries) -- longer lists use the global scratch
+	RegKey *keys; int *idx; int *stk;                            // sort scratch
+	uint8_t *tw; int tw_cap;                                     // reference window in LDS when it fits (a dependent global load per DP column costs ~1 us)
+	uint16_t *cm;                                                // column maxima (tw_cap entries) in LDS for the same reason
 };
 
 // mem_sort_dedup_patch with bns == 0 (no patching), as mem_matesw calls it (bwamem_pair.c:203; bwamem.c:444-496).
 // L: the list (n entries), tmp: a spare list of the same capacity, keys / idx: sort scratch (n and 2n entries).
-__device__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp, RegKey *keys, int *idx, int *stk, int l, int *err)
+__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp, RegKey *keys, int *idx, int *stk, int l, int *err)
 {
 	if (n <= 1) return n;
 	for (int i = l; i < n; i += 64) { keys[i].k64 = L[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
@@ -201,7 +203,7 @@ __device__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp
 // mem_matesw (bwamem_pair.c:137-206): anchor `an` (a region of one end), mate read r_m (length l_ms), mate list L (n_ma).
 // P = 16: byte kernel (l_ms * a < 250), P = 8: word kernel.  Returns the new length of the mate list.
 template <int P>
-__device__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, DevReg *L, int n_ma, DevReg *tmp, RegKey *keys, int *idx,
+__device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, DevReg *L, int n_ma, DevReg *tmp, RegKey *keys, int *idx,
                       const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new)
 {
 	const DevOpt &opt = a.opt;
@@ -222,7 +224,6 @@ __device__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, D
 	if (skip == 15) return n_ma;
 	const uint8_t *ms = a.seq + a.off[r_m];
 	int n = 0;
-	uint8_t *s_t = slab;                                          // reference window (global scratch of this workgroup)
 	for (int r = 0; r < 4; ++r) {
 		if (skip >> r & 1) continue;
 		const int is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);
@@ -247,24 +248,32 @@ __device__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, D
 			re = re < far_end ? re : far_end;
 		}
 		if (an.rid == rid && re - rb >= opt.min_seed_len) {
+			const unsigned long long tk0 = wall_clock64();
 			const int tlen = (int)(re - rb);
+			uint8_t *s_t = tlen <= m.tw_cap ? m.tw : slab;             // reference window: LDS, or this workgroup's global scratch when too wide
 			__syncthreads();
 			for (int i = l; i < tlen; i += 64) s_t[i] = (uint8_t)ref_base(ix, rb + i);
 			if (is_rev) for (int i = l; i < l_ms; i += 64) { const uint8_t c = ms[i]; m.q[l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
 			else for (int i = l; i < l_ms; i += 64) m.q[i] = ms[i];
 			wsync();
+			const unsigned long long tk1 = wall_clock64();
 			const int xtra = ssw::XSUBO | ssw::XSTART | (P == 16 ? ssw::XBYTE : 0) | (opt.min_seed_len * opt.a);
 			ssw::Res aln = { 0, -1, -1, -1, -1, -1, -1 };
 			if (l < P) {                                          // one group of the wavefront runs the alignment
 				const int cells = (l_ms + P - 1) / P * P;
 				ssw::Work w;
 				w.prof = m.prof; w.H0 = m.h; w.H1 = m.h + cells; w.E = m.h + 2 * cells; w.Hmax = m.h + 3 * cells;
-				w.colmax = reinterpret_cast<uint16_t*>(slab + ((size_t)tlen + 63) / 64 * 64);
-				aln = ssw::align2<P>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+				w.colmax = tlen <= m.tw_cap ? m.cm : reinterpret_cast<uint16_t*>(slab + ((size_t)tlen + 63) / 64 * 64);
+				// byte kernel: at most 16 segments (249 bases); 10 covers reads up to 160 bases
+				if (P == 16 && l_ms <= 160) aln = ssw::align2<P, 10>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+				else if (P == 16) aln = ssw::align2<P, 16>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+				else aln = ssw::align2<P>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
 			}
 			aln.score = __shfl(aln.score, 0); aln.te = __shfl(aln.te, 0); aln.qe = __shfl(aln.qe, 0); aln.score2 = __shfl(aln.score2, 0);
 			aln.tb = __shfl(aln.tb, 0); aln.qb = __shfl(aln.qb, 0);
 			++n_sw;
+			const unsigned long long tk2 = wall_clock64();
+			if (l == 0) { atomicAdd(&a.counters[4], tk1 - tk0); atomicAdd(&a.counters[5], tk2 - tk1); }
 			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {   // something goes wrong if aln.qb < 0 (bwamem_pair.c:178)
 				DevReg b;
 				memset(&b, 0, sizeof b);
@@ -297,7 +306,7 @@ __device__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, D
 			}
 			++n;
 		}
-		if (n) n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, l, a.err);
+		if (n) { const unsigned long long tk3 = wall_clock64(); n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, l, a.err); if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }
 	}
 	return n_ma;
 }
@@ -311,28 +320,54 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 	__shared__ int8_t s_prof[5 * CELLS];
 	__shared__ int16_t s_h[4 * CELLS];
 	__shared__ int s_stk[3 * 80];
+	__shared__ uint8_t s_tw[4096];
+	__shared__ uint16_t s_cm[4096];
+	// 16-byte aligned: the lists are reached through generic pointers (LDS or global slots), i.e. flat 16-byte accesses
+	__shared__ __attribute__((aligned(16))) DevReg s_list_g[MS_LIST + 2];   // one spare record in front and behind (folded address offsets stay inside LDS)
+	__shared__ __attribute__((aligned(16))) DevReg s_tmp_g[MS_LIST + 2];
+	__shared__ __attribute__((aligned(16))) RegKey s_keys[MS_LIST];
+	DevReg *const s_list = s_list_g + 1, *const s_tmp = s_tmp_g + 1;
+	__shared__ int s_idx[2 * MS_LIST];
 	const int l = lane();
 	if (l < 25) s_mat[l] = a.opt.mat[l];
 	__syncthreads();
 	uint8_t *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
-	unsigned long long n_sw = 0, n_new = 0;
+	unsigned long long n_sw = 0, n_new = 0, max_sw = 0;
 	const int n_resc = *a.resc_n;
 	for (int it = (int)blockIdx.x; it < n_resc; it += (int)gridDim.x) {
 		const int p = a.resc_list[it];
+		const unsigned long long sw_before = n_sw, tp0 = wall_clock64();
 		int n_list[2] = { a.pe_n[p << 1], a.pe_n[p << 1 | 1] };
 		// sort scratch of a list lives behind its slots' spare copy: tmp list, keys and index arrays sized by the capacity
 		for (int i = 0; i < 2; ++i) {
 			const int r = p << 1 | i, rm = r ^ 1;
 			const int l_ms = (int)(a.off[rm + 1] - a.off[rm]);
 			if ((P == 16) != (l_ms * a.opt.a < 250)) continue;    // the other instantiation takes this mate length
-			DevReg *L = a.pe_regs + a.pe_base[rm];
-			DevReg *tmp = a.pe_tmp + a.pe_base[rm];
-			RegKey *keys = reinterpret_cast<RegKey*>(a.pe_keys) + a.pe_base[rm];
-			int *idx = a.pe_idx + 2 * a.pe_base[rm];
-			const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk };
+			if (a.nb[r] == 0) continue;
+			// the mate's list is worked on in LDS when its capacity fits (the insert / sort / dedup steps are chains of dependent
+			// accesses: ~1 ms per rescue through global memory, measured), else in its global slots
+			DevReg *G = a.pe_regs + a.pe_base[rm];
+			const bool in_lds = a.pe_cap[rm] <= MS_LIST;
 			const DevReg *snap = a.regs + a.reg_base[r];            // b[i]: the end's own regions as mem_align1_core left them
-			for (int j = 0; j < a.nb[r]; ++j)
-				n_list[i ^ 1] = matesw<P>(a, snap[j], rm, l_ms, L, n_list[i ^ 1], tmp, keys, idx, m, slab, l, n_sw, n_new);
+			// two call sites on purpose: each is compiled for its own address space (LDS / global).  Through one generic pointer the
+			// list code became flat instructions with folded offsets (base = &L[i-1], offset +80); the hardware picks the aperture
+			// from the base alone, and &s_list[-1] lies outside the LDS aperture: a memory violation (seen under rocgdb).
+			if (in_lds) {
+				__syncthreads();
+				for (int k = l; k < n_list[i ^ 1]; k += 64) s_list[k] = G[k];
+				wsync();
+				const MsLds m = { s_q, s_mat, s_prof, s_h, s_keys, s_idx, s_stk, s_tw, 4096, s_cm };
+				for (int j = 0; j < a.nb[r]; ++j)
+					n_list[i ^ 1] = matesw<P>(a, snap[j], rm, l_ms, s_list, n_list[i ^ 1], s_tmp, s_keys, s_idx, m, slab, l, n_sw, n_new);
+			} else {
+				DevReg *tmp = a.pe_tmp + a.pe_base[rm];
+				RegKey *keys = reinterpret_cast<RegKey*>(a.pe_keys) + a.pe_base[rm];
+				int *idx = a.pe_idx + 2 * a.pe_base[rm];
+				const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk, s_tw, 4096, s_cm };
+				for (int j = 0; j < a.nb[r]; ++j)
+					n_list[i ^ 1] = matesw<P>(a, snap[j], rm, l_ms, G, n_list[i ^ 1], tmp, keys, idx, m, slab, l, n_sw, n_new);
+			}
+			if (in_lds) { wsync(); for (int k = l; k < n_list[i ^ 1]; k += 64) G[k] = s_list[k]; wsync(); }
 		}
 		if (l == 0) {
 			const int lm0 = (int)(a.off[(p << 1) + 1] - a.off[p << 1]), lm1 = (int)(a.off[(p << 1) + 2] - a.off[(p << 1) + 1]);
@@ -340,9 +375,11 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 			if ((P == 16) == (lm1 * a.opt.a < 250)) a.pe_n[p << 1 | 1] = n_list[1];
 			if ((P == 16) == (lm0 * a.opt.a < 250)) a.pe_n[p << 1] = n_list[0];
 		}
+		max_sw = max_sw > n_sw - sw_before ? max_sw : n_sw - sw_before;
+		if (l == 0) atomicMax(&a.counters[7], wall_clock64() - tp0);
 		__syncthreads();
 	}
-	if (l == 0 && n_sw) { atomicAdd(&a.counters[0], n_sw); atomicAdd(&a.counters[1], n_new); }
+	if (l == 0) { if (n_sw) { atomicAdd(&a.counters[0], n_sw); atomicAdd(&a.counters[1], n_new); atomicMax(&a.counters[2], max_sw); } if (blockIdx.x == 0) atomicMax(&a.counters[3], (unsigned long long)n_resc); }
 }
 
 // ---------------------------------------------------------------------------------------------------- mem_pair + mem_sam_pe decisions

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void k_sam_se(FinLaunch a)
 	Emit e = { WRITE ? a.sam + a.sam_off[r] : nullptr, 0, l };
 	if (n_rec == 0) {
 		// unaligned read (bwamem.c:1043-1047): mem_reg2aln(..., 0) gives rid = pos = -1, flag 0x4, everything else 0
-		__shared__ DevAln s_un;
+		__shared__ __attribute__((aligned(16))) DevAln s_un;
 		__shared__ const DevAln *s_unp;
 		if (l == 0) {
 			DevAln u;
@@ -94,7 +94,7 @@ __device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, 
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_sam_pe(FinLaunch a)
 {
-	__shared__ DevAln s_un[2];                                    // [0] unaligned record of this read, [1] unaligned mate
+	__shared__ __attribute__((aligned(16))) DevAln s_un[2];      // [0] unaligned record of this read, [1] unaligned mate (DevAln is padded to 80 bytes)
 	__shared__ const DevAln *s_unp;
 	const int r = blockIdx.x, l = lane(), rm = r ^ 1, end = r & 1;
 	const DevOpt &opt = a.opt;

@@ -119,7 +119,8 @@ __device__ void kat_item(const int8_t *mat, const int *p, const uint8_t *q, cons
 	w.H0 = (int16_t*)(wsp + 5 * (size_t)cells + 8 - (5 * (size_t)cells) % 8);
 	w.H1 = w.H0 + cells; w.E = w.H1 + cells; w.Hmax = w.E + cells;
 	w.colmax = (uint16_t*)(w.Hmax + cells);
-	const ssw::Res r = ssw::align2<P>(w, lane, qlen, q, 1, tlen, t, 1, mat, p[3], p[4], p[5], p[6], p[2]);
+	// queries of up to 16 segments take the register-resident variant (as k_matesw does), longer ones the LDS/global one
+	const ssw::Res r = ssw::align2<P, 16>(w, lane, qlen, q, 1, tlen, t, 1, mat, p[3], p[4], p[5], p[6], p[2]);
 	if ((lane & (P - 1)) == 0) { out7[0] = r.score; out7[1] = r.te; out7[2] = r.qe; out7[3] = r.score2; out7[4] = r.te2; out7[5] = r.tb; out7[6] = r.qb; }
 }
 __global__ __launch_bounds__(64) void k_kat_align(DevOpt opt, int n, int byte_mode, const int *items, const int *params, const uint8_t *q, const int64_t *qoff,

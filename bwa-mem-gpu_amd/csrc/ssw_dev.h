@@ -171,9 +171,114 @@ __device__ __forceinline__ Res pass(const Work &w, int lane, int slen, int shift
 	return r;
 }
 
+// The same pass with the H / E / Hmax cells of a lane in REGISTERS (segments fully unrolled up to SLEN): the DP column is a
+// chain of dependent steps, and with the cells in LDS every step waits for an LDS round trip (~1 900 cycles per column
+// measured with 10 segments); in registers only the profile row comes from LDS, and its loads do not depend on the chain.
+// Exactly the arithmetic of pass<>; w.H0/H1/E are not touched, w.Hmax receives the best column at the end (for callers
+// that want it; qe is computed here).
+template <int P, int SLEN>
+__device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int shift, int qmax, int tlen, const SeqView &t,
+                                        int o_del, int e_del, int o_ins, int e_ins, int minsc, int endsc)
+{
+	constexpr bool is8 = P == 16;
+	const int gl = gl_of<P>(lane);
+	int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	if (is8) { oe_del &= 0xff; oe_ins &= 0xff; e_del &= 0xff; e_ins &= 0xff; }
+	else { oe_del &= 0xffff; oe_ins &= 0xffff; e_del &= 0xffff; e_ins &= 0xffff; }
+	int H[SLEN], E[SLEN], Hm[SLEN];
+#pragma unroll
+	for (int j = 0; j < SLEN; ++j) { H[j] = 0; E[j] = 0; Hm[j] = 0; }
+	int gmax = 0, te = -1, n_cols = 0;
+	for (int i = 0; i < tlen; ++i) {
+		const int8_t *S = w.prof + (size_t)t.at(i) * slen * P;
+		int sv[SLEN];
+#pragma unroll
+		for (int j = 0; j < SLEN; ++j) sv[j] = j < slen ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
+		int f = 0, mxv = 0, last = 0;
+#pragma unroll
+		for (int j = 0; j < SLEN; ++j) if (j == slen - 1) last = H[j];
+		int h = shift_up<P>(last, gl);
+#pragma unroll
+		for (int j = 0; j < SLEN; ++j) {
+			if (j < slen) {
+				int e = E[j];
+				if (is8) { h += sv[j]; h = h > 255 ? 255 : h; h = sat_sub_u(h, shift); }
+				else { h += sv[j]; h = h > 32767 ? 32767 : h < -32768 ? -32768 : h; }
+				h = h > e ? h : e;
+				h = h > f ? h : f;
+				mxv = mxv > h ? mxv : h;
+				const int h_old = H[j];
+				H[j] = h;
+				e = sat_sub_u(e, e_del);
+				int tt = sat_sub_u(h, oe_del);
+				E[j] = e > tt ? e : tt;
+				f = sat_sub_u(f, e_ins);
+				tt = sat_sub_u(h, oe_ins);
+				f = f > tt ? f : tt;
+				h = h_old;
+			}
+		}
+		bool stop = false;
+		for (int k = 0; k < 16 && !stop; ++k) {                     // lazy-F (ksw.c:179-190 / 287-297)
+			f = shift_up<P>(f, gl);
+#pragma unroll
+			for (int j = 0; j < SLEN; ++j) {
+				if (j < slen && !stop) {
+					int hh = H[j];
+					hh = hh > f ? hh : f;
+					H[j] = hh;
+					hh = sat_sub_u(hh, oe_ins);
+					f = sat_sub_u(f, e_ins);
+					if (!group_any<P>(f > hh, lane)) stop = true;
+				}
+			}
+		}
+		const int imax = group_max<P>(mxv);
+		if (w.colmax && gl == 0) w.colmax[i] = (uint16_t)imax;
+		n_cols = i + 1;
+		if (imax > gmax) {
+			gmax = imax; te = i;
+#pragma unroll
+			for (int j = 0; j < SLEN; ++j) Hm[j] = H[j];
+			if (is8 ? (gmax + shift >= 255 || gmax >= endsc) : gmax >= endsc) break;
+		}
+	}
+	Res r = { 0, -1, -1, -1, -1, -1, -1 };
+	r.score = is8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+	r.te = te;
+	if (!is8 || r.score != 255) {
+		int best = -1;
+#pragma unroll
+		for (int j = 0; j < SLEN; ++j) if (j < slen) { const int v = Hm[j] & 0xffff; best = best > v ? best : v; }
+		best = group_max<P>(best);
+		int qe = 1 << 30;
+#pragma unroll
+		for (int j = 0; j < SLEN; ++j) if (j < slen && (Hm[j] & 0xffff) == best) { const int k = j + gl * slen; qe = qe < k ? qe : k; }
+		qe = group_min<P>(qe);
+		r.qe = slen > 0 ? qe : -1;
+		if (minsc < 0x10000 && w.colmax) {
+			__threadfence_block();
+			const int span = (r.score + qmax - 1) / qmax, low = te - span, high = te + span;
+			int cur_m = -1, cur_i = -1;
+			bool have = false;
+			for (int i = 0; i < n_cols; ++i) {
+				const int m = w.colmax[i];
+				if (m < minsc) continue;
+				if (!have || cur_i + 1 != i) {
+					if (have && (cur_i < low || cur_i > high) && cur_m > r.score2) { r.score2 = cur_m; r.te2 = cur_i; }
+					cur_m = m; cur_i = i; have = true;
+				} else if (cur_m < m) { cur_m = m; cur_i = i; }
+			}
+			if (have && (cur_i < low || cur_i > high) && cur_m > r.score2) { r.score2 = cur_m; r.te2 = cur_i; }
+		}
+	}
+	return r;
+}
+
 // ksw_align2 (ksw.c:343-365).  q / t are plain (unreversed) views; `mat` 5x5.  Group-collective; the caller provides
 // the group's working set and separates consecutive calls that reuse it with a wavefront barrier.
-template <int P>
+// SLEN > 0: cells in registers (pass_reg) when the query has at most SLEN segments, else the LDS version.
+template <int P, int SLEN = 0>
 __device__ __forceinline__ Res align2(const Work &w, int lane, int qlen, const uint8_t *q, int qstride, int tlen, const uint8_t *t, int tstride,
                                       const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra)
 {
@@ -182,14 +287,17 @@ __device__ __forceinline__ Res align2(const Work &w, int lane, int qlen, const u
 	SeqView qv = { q, qstride, 0 }, tv = { t, tstride, 0 };
 	qinit<P>(w, gl, qlen, qv, mat, slen, shift, qmax);
 	const int minsc = (xtra & XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & XSTOP) ? xtra & 0xffff : 0x10000;
-	Res r = pass<P, true>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc);
+	const bool in_regs = SLEN > 0 && slen <= SLEN;
+	Res r = in_regs ? pass_reg<P, SLEN ? SLEN : 1>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc)
+	                : pass<P, true>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc);
 	if ((xtra & XSTART) == 0 || ((xtra & XSUBO) && r.score < (xtra & 0xffff))) return r;
 	if (P == 16 && r.score == 255) return r;                      // qe unknown: the reference reads out of bounds here; unreachable (score <= qlen*a < 250)
 	// second pass on the reversed prefixes to find the start (ksw.c:356-363); it scans tlen columns, not te+1
 	qv.rev_n = r.qe + 1; tv.rev_n = r.te + 1;
 	Work w2 = w; w2.colmax = nullptr;
 	qinit<P>(w2, gl, r.qe + 1, qv, mat, slen, shift, qmax);
-	const Res rr = pass<P, true>(w2, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, 0x10000, r.score & 0xffff);
+	const Res rr = in_regs ? pass_reg<P, SLEN ? SLEN : 1>(w2, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, 0x10000, r.score & 0xffff)
+	                       : pass<P, true>(w2, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, 0x10000, r.score & 0xffff);
 	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
 	return r;
 }

@@ -196,8 +196,9 @@ int bwahip_align_batch(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, bwahip_s
 int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);
 
 /* Insert-size statistics (mem_pestat_t[4]: FF, FR, RF, RR; bwamem_pair.c:72) and mate-rescue counters ([0] local alignments
- * run, [1] regions added; bwamem_pair.c:137) of the last paired-end batch finalised on the GPU.  Either pointer may be NULL. */
-int bwahip_last_pe_stats(bwahip_ctx *ctx, bwahip_pestat_t *pes4, uint64_t *counters2);
+ * run, [1] regions added, [2] most alignments of one pair, [3] pairs that needed any; bwamem_pair.c:137) of the last
+ * paired-end batch finalised on the GPU.  Either pointer may be NULL; counters4 receives 4 values. */
+int bwahip_last_pe_stats(bwahip_ctx *ctx, bwahip_pestat_t *pes4, uint64_t *counters4);
 
 /* Concatenate seqs[0..n).sam into one malloc()ed buffer (read order; *out_len bytes + a NUL) and free the per-read strings. */
 int bwahip_seqs_take_sam(bwahip_seq_t *seqs, int n, char **out, int64_t *out_len);
