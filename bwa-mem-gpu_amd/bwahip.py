@@ -95,6 +95,8 @@ def lib():
     L.bwahip_ctx_tune.argtypes = [vp, C.c_char_p, C.c_int]
     L.bwahip_kat_ksw_align.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.bwahip_init_from_files.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.bwahip_rccl_unique_id.argtypes = [vp]
+    L.bwahip_init_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
     L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
@@ -187,6 +189,21 @@ class Context:
         n.l_pac, n.n_seqs, n.seed, n.anns = meta["l_pac"], len(meta["contigs"]), 11, anns
         self._keep = (b, anns, n)
         _check(lib().bwahip_init_device(C.byref(b), C.byref(n), pac_ptr, device, C.byref(self._h)), "bwahip_init_device")
+        return self
+
+    @staticmethod
+    def rccl_unique_id():
+        """128-byte ncclUniqueId (made on one rank; hand it to the others before from_rccl)."""
+        buf = C.create_string_buffer(128)
+        _check(lib().bwahip_rccl_unique_id(buf), "bwahip_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_rccl(cls, prefix, rank, world, unique_id, device=0):
+        """Collective: rank 0 loads `prefix`, all ranks receive the index over RCCL into their own HBM (bwahip_init_rccl)."""
+        self = cls(None, device)
+        idb = C.create_string_buffer(bytes(unique_id), 128)
+        _check(lib().bwahip_init_rccl(os.fsencode(prefix) if prefix is not None else None, rank, world, idb, device, C.byref(self._h)), "bwahip_init_rccl")
         return self
 
     def close(self):

@@ -66,6 +66,7 @@ struct Knobs {
 
 struct bwahip_ctx {
 	bool external_index = false;
+	bool index_resident = false;         // d_bwt / d_sa / d_pac were filled before ctx_setup (bwahip_init_rccl)
 	Knobs knobs;
 	std::string rg_id;                   // read-group id appended as RG:Z: to every record (bwa_rg_id, bwa.c:44); empty = none
 	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
@@ -104,6 +105,7 @@ struct bwahip_ctx {
 };
 
 
+extern "C" int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac);   // streams, tables, DevIndex
 int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st);   // exclusive scan int32 -> int64, n+1 outputs
 int dev_upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st);
 int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump);      // the hot path over the uploaded batch

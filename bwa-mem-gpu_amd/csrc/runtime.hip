@@ -150,7 +150,7 @@ int dev_upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
 static inline int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) { return dev_upload(b, src, bytes, st); }
 extern "C" {
 
-static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac)
+int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac)
 {
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -170,6 +170,7 @@ static int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t 
 	}
 	if (c->external_index) {             // adopt caller-owned device arrays (e.g. received over RCCL)
 		c->d_bwt.p = bwt->bwt; c->d_sa.p = bwt->sa; c->d_pac.p = (void*)pac;
+	} else if (c->index_resident) {      // bwahip_init_rccl: the context's own buffers were filled by the broadcast
 	} else {
 		if ((rc = upload(c->d_bwt, bwt->bwt, bwt->bwt_size * 4, c->stream))) return rc;
 		if ((rc = upload(c->d_sa, bwt->sa, bwt->n_sa * 8, c->stream))) return rc;

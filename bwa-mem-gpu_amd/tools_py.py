@@ -226,3 +226,29 @@ def broadcast_index(bw, dist, torch, prefix, rank, local_rank):
     torch.cuda.synchronize()
     ctx = bw.Context.from_device_arrays(meta, tensors["bwt"].data_ptr(), tensors["sa"].data_ptr(), tensors["pac"].data_ptr(), local_rank)
     return ctx, tensors
+
+
+# ------------------------------------------------------------------------------------------ read sharding over ranks
+def shard_batches(n_reads, batch_reads, rank, world):
+    """Whole mem_process_seqs batches round-robin over the ranks: [(batch index, first read, end read)] of `rank`.
+    A batch keeps its true n_processed (= first read), so hash tie-breaks and per-batch insert-size statistics are those of
+    a single-process run with the same -K."""
+    out = []
+    for b, b0 in enumerate(range(0, n_reads, batch_reads)):
+        if b % world == rank:
+            out.append((b, b0, min(n_reads, b0 + batch_reads)))
+    return out
+
+
+def align_sharded(dist, rank, world, n_reads, batch_reads, align_batch):
+    """Every rank runs align_batch(first, end, n_processed) -> bytes on its batches; rank 0 returns the SAM of all batches in
+    input order (the others return None).  No data-path collective: only the final gather of the text."""
+    mine = [(b, align_batch(b0, b1, b0)) for b, b0, b1 in shard_batches(n_reads, batch_reads, rank, world)]
+    if world == 1:
+        return b"".join(t for _, t in sorted(mine))
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    if rank != 0:
+        return None
+    allb = sorted(x for part in gathered for x in part)
+    return b"".join(t for _, t in allb)

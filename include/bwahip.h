@@ -168,6 +168,12 @@ int  bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t
  * broadcast from the rank that loaded the index); the device arrays stay owned by the caller and must outlive the
  * ctx.  bns is a host struct; the packed reference is read back once (l_pac/4+1 bytes) for host-side finalisation. */
 int  bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out);
+/* One process per GPU on one node: rank 0 reads the index files, every rank receives the three index arrays and the contig
+ * table over RCCL (xGMI) into its own HBM and gets a context on them -- what transferIndex() (cuda/streams.cu:8) does for
+ * one GPU.  id128: a 128-byte ncclUniqueId made by bwahip_rccl_unique_id() on one rank and handed to the others by the
+ * caller's own means (MPI, a file, torch.distributed ...).  prefix is read on rank 0 only.  Collective: every rank calls it. */
+int  bwahip_rccl_unique_id(void *id128);
+int  bwahip_init_rccl(const char *prefix, int rank, int world, const void *id128, int device, bwahip_ctx **out);
 /* Convenience: read a stock `bwa index` file set <prefix>.{bwt,sa,pac,ann,amb[,alt]} (bwa.c:402 bwa_idx_load) and init. */
 int  bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out);
 void bwahip_destroy(bwahip_ctx *ctx);
