@@ -118,13 +118,33 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    if rank == 0 or world == 1:
+    holder = None
+    index_distribution = "bwahip_init_from_files"
+    if world == 1:
         ctx = bw.Context(prefix, local_rank)
-        holder = None
-    if world > 1:
-        ctx_or_holder = tp.broadcast_index(bw, dist, torch, prefix if rank == 0 else None, rank, local_rank)
-        if rank != 0:
-            ctx, holder = ctx_or_holder
+    else:
+        # rank 0 reads the files, every rank receives the index over RCCL into its own HBM (bwahip_init_rccl, the C ABI's collective);
+        # the 128-byte RCCL id travels over the already initialised torch.distributed group
+        box = [bw.Context.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            ctx = bw.Context.from_rccl(prefix if rank == 0 else None, rank, world, box[0], local_rank)
+            index_distribution = "bwahip_init_rccl (ncclBroadcast x4 inside libbwahip.so)"
+            ok = 1
+        except bw.BwahipError as e:
+            log(f"rank {rank}: bwahip_init_rccl failed ({e}); falling back to torch.distributed broadcast + bwahip_init_device")
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:                                   # any rank failed: everybody takes the torch.distributed path
+            if ok:
+                ctx.close()
+            index_distribution = "torch.distributed broadcast + bwahip_init_device"
+            if rank == 0:
+                ctx = bw.Context(prefix, local_rank)
+            ctx_or_holder = tp.broadcast_index(bw, dist, torch, prefix if rank == 0 else None, rank, local_rank)
+            if rank != 0:
+                ctx, holder = ctx_or_holder
     t_bcast = time.time() - t0
     log(f"rank {rank}: index resident in HBM ({t_bcast:.1f}s)")
 
@@ -251,7 +271,7 @@ def main():
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "read_len": rl, "paired": pe, "genome_mbp": args.genome_mbp,
                        "stages": ctx.stage_names(),
                        "output": ctx.output_description(pe),
-                       "index_build_s": round(t_index, 1), "index_to_hbm_s": round(t_bcast, 2), "host_cpus_usable": cpus},
+                       "index_build_s": round(t_index, 1), "index_to_hbm_s": round(t_bcast, 2), "index_distribution": index_distribution, "host_cpus_usable": cpus},
             "kernel_ms": {k: round(float(np.mean([x[k] for x in kms])), 3) for k in kms[0]},
             "launches_timed": n_launch, "sam_bytes_per_batch": sam_bytes,
             "per_read": {"bwt_extend": round(counters["extend"] / args.reads, 1), "occ_blocks": round(counters["blocks"] / args.reads, 1),

@@ -247,6 +247,7 @@ struct PeRead {
 	int extra_flag;    // 0x1 | 0x2 (proper pair)
 	int pad[3];
 };
+struct SwRes { int state /* 0 none, 1 queued, 2 done */, score, te, qe, score2, te2, tb, qb; };
 struct PairLaunch {
 	DevIndex ix; DevOpt opt;
 	int n_reads; const uint8_t *seq; const int64_t *off;
@@ -262,6 +263,9 @@ struct PairLaunch {
 	DevReg *pe_regs; int *pe_n;                  // the lists mem_sam_pe works on
 	DevReg *pe_tmp; void *pe_keys; int *pe_idx;  // sort scratch of a list at its slots: spare list, 16-byte keys, 2 ints per slot
 	int *resc_list; int *resc_n;                 // pairs that need at least one Smith-Waterman
+	// the alignments of the anchors that need one on the lists as mem_align1_core left them, done ahead of the sequential pass,
+	// four per wavefront (k_matesw_sw): slot = sw_base[anchor's read] + 4 * anchor + orientation
+	const int64_t *sw_base; int *sw_cnt; SwRes *sw_res; int *sw_tasks; int2 *sw_info; int *sw_n;
 	uint8_t *slab; size_t slab_stride;           // k_matesw: per-workgroup global scratch (reference window, column maxima, long-query working set)
 	unsigned long long *counters;                // [0] SW calls, [1] rescued regions
 	// pairing
@@ -275,6 +279,7 @@ int launch_pestat(const PairLaunch &a, hipStream_t st);
 int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
 int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
+int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st);
 int launch_pair(const PairLaunch &a, hipStream_t st);
 size_t matesw_slab_bytes(int64_t window);
 int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st);

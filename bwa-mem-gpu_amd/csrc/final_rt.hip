@@ -76,7 +76,7 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	pl.logtab = c->d_logtab.as<double>();
 	pl.regs = c->d_regs.as<DevReg>(); pl.reg_base = c->d_reg_base.as<int64_t>(); pl.reg_n = c->d_reg_n.as<int>();
 	unsigned long long *fm = c->d_fmisc.as<unsigned long long>();
-	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5;
+	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5; pl.sw_n = (int*)(fm + 14);
 	bwahip_pestat_t pes[4];
 	if (pes0) memcpy(pes, pes0, sizeof pes);
 	else {
@@ -111,21 +111,32 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	pl.pair_tab = c->d_pair_tab.as<double>();
 	// list capacities after rescue
 	if ((rc = c->d_nb.ensure((size_t)n * 4)) || (rc = c->d_pe_cap.ensure((size_t)n * 4)) || (rc = c->d_pe_base.ensure((size_t)(n + 1) * 8)) || (rc = c->d_pe_n.ensure((size_t)n * 4)) ||
-	    (rc = c->d_resc.ensure((size_t)(n / 2 + 4) * 4))) return rc;
+	    (rc = c->d_resc.ensure((size_t)(n / 2 + 4) * 4)) || (rc = c->d_sw_cnt.ensure((size_t)n * 4)) || (rc = c->d_sw_base.ensure((size_t)(n + 1) * 8))) return rc;
+	pl.sw_cnt = c->d_sw_cnt.as<int>(); pl.sw_base = c->d_sw_base.as<int64_t>();
 	pl.nb = c->d_nb.as<int>(); pl.pe_cap = c->d_pe_cap.as<int>(); pl.pe_base = c->d_pe_base.as<int64_t>(); pl.pe_n = c->d_pe_n.as<int>(); pl.resc_list = c->d_resc.as<int>();
 	if ((rc = launch_pe_prepare(pl, c->stream))) return rc;
 	if ((rc = launch_scan(pl.pe_cap, c->d_pe_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
-	int64_t cap = 0;
+	if ((rc = launch_scan(pl.sw_cnt, c->d_sw_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
+	int64_t cap = 0, n_slots = 0;
 	HIP_TRY(hipMemcpyAsync(&cap, c->d_pe_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&n_slots, c->d_sw_base.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	{
+		const size_t S = (size_t)(n_slots ? n_slots : 1);
+		if ((rc = c->d_sw_res.ensure(S * sizeof(SwRes))) || (rc = c->d_sw_tasks.ensure(S * 4)) || (rc = c->d_sw_info.ensure(S * 8))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_sw_res.p, 0, S * sizeof(SwRes), c->stream));
+		pl.sw_res = c->d_sw_res.as<SwRes>(); pl.sw_tasks = c->d_sw_tasks.as<int>(); pl.sw_info = c->d_sw_info.as<int2>();
+	}
 	const size_t R = (size_t)(cap ? cap : 1);
 	c->total_regs = cap;                                          // from here on the region slots are the paired-end ones
 	if ((rc = c->d_pe_regs.ensure(R * sizeof(DevReg))) || (rc = c->d_pe_tmp.ensure(R * sizeof(DevReg))) || (rc = c->d_pe_keys.ensure(R * 16)) || (rc = c->d_pe_idx.ensure(R * 8))) return rc;
 	pl.pe_regs = c->d_pe_regs.as<DevReg>(); pl.pe_tmp = c->d_pe_tmp.as<DevReg>(); pl.pe_keys = c->d_pe_keys.p; pl.pe_idx = c->d_pe_idx.as<int>();
 	if ((rc = launch_pe_copy(pl, c->stream))) return rc;
-	int n_resc = 0;
+	int n_resc = 0, n_sw_tasks = 0;
 	HIP_TRY(hipMemcpyAsync(&n_resc, pl.resc_n, 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&n_sw_tasks, pl.sw_n, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->stream))) return rc;   // the alignments against the unrescued lists, all at once
 	if (n_resc > 0) {
 		const int grid = std::min(n_resc, 2048);
 		pl.slab_stride = (matesw_slab_bytes(widest + c->max_len) + 255) & ~(size_t)255;
@@ -133,10 +144,10 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 		pl.slab = c->d_ms_slab.as<uint8_t>();
 		if ((rc = launch_matesw(pl, grid, c->stream))) return rc;
 	}
-	HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 64, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 72, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->last_pe_counters[3] = (unsigned long long)n_resc;
-	if (c->knobs.verbose) fprintf(stderr, "[bwahip] mate rescue: %llu SW, %llu added, max %llu per pair, %d pairs; ticks(10ns) window %llu sw %llu dedup %llu, slowest pair %llu\n", c->last_pe_counters[0], c->last_pe_counters[1], c->last_pe_counters[2], n_resc, c->last_pe_counters[4], c->last_pe_counters[5], c->last_pe_counters[6], c->last_pe_counters[7]);
+	if (c->knobs.verbose) fprintf(stderr, "[bwahip] mate rescue: %llu SW, %llu added, max %llu per pair, %d pairs, %llu aligned inside the sequential pass; ticks(10ns) window %llu sw %llu dedup %llu, slowest pair %llu\n", c->last_pe_counters[0], c->last_pe_counters[1], c->last_pe_counters[2], n_resc, c->last_pe_counters[8], c->last_pe_counters[4], c->last_pe_counters[5], c->last_pe_counters[6], c->last_pe_counters[7]);
 	return 0;
 }
 

@@ -85,7 +85,7 @@ __global__ void k_pe_prepare(PairLaunch a)
 			for (int j = 0; j < n; ++j) c += l[j].score >= thr ? 1 : 0;   // the list is sorted by score: a prefix
 			c = c < a.opt.max_matesw ? c : a.opt.max_matesw;
 		}
-		nb[i] = c; a.nb[r] = c;
+		nb[i] = c; a.nb[r] = c; a.sw_cnt[r] = 4 * c;
 	}
 	a.pe_cap[p << 1] = a.reg_n[p << 1] + nb[1] * n_live;
 	a.pe_cap[p << 1 | 1] = a.reg_n[p << 1 | 1] + nb[0] * n_live;
@@ -104,6 +104,37 @@ __device__ __forceinline__ int skip_mask_seq(const PairLaunch &a, int64_t arb, c
 	return m;
 }
 
+// the reference window of mem_matesw for anchor `an`, orientation r and a mate of l_ms bases (bwamem_pair.c:153-166);
+// true when the alignment is attempted (same contig as the anchor, window at least one seed long)
+__device__ __forceinline__ bool ms_window(const PairLaunch &a, const DevReg &an, int r, int l_ms, int64_t &rb, int64_t &re)
+{
+	const DevIndex &ix = a.ix;
+	const int64_t l_pac = ix.l_pac;
+	const int is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);
+	if (!is_rev) {
+		rb = is_larger ? an.rb + a.pes[r].low : an.rb - a.pes[r].high;
+		re = (is_larger ? an.rb + a.pes[r].high : an.rb - a.pes[r].low) + l_ms;
+	} else {
+		rb = (is_larger ? an.rb + a.pes[r].low : an.rb - a.pes[r].high) - l_ms;
+		re = is_larger ? an.rb + a.pes[r].high : an.rb - a.pes[r].low;
+	}
+	if (rb < 0) rb = 0;
+	if (re > l_pac << 1) re = l_pac << 1;
+	int rid = -1;
+	if (rb < re) {                                                // bns_fetch_seq (bntseq.c:426): clamp to the contig holding the middle
+		const int64_t mid = (rb + re) >> 1;
+		const bool mrev = mid >= l_pac;
+		rid = dev_pos2rid(ix, mrev ? (l_pac << 1) - 1 - mid : mid);
+		int64_t far_beg = ix.anns[rid].offset, far_end = far_beg + ix.anns[rid].len;
+		if (mrev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+		rb = rb > far_beg ? rb : far_beg;
+		re = re < far_end ? re : far_end;
+	}
+	return an.rid == rid && re - rb >= a.opt.min_seed_len;
+}
+
+constexpr int SW_TW = 1024;                                  // widest window k_matesw_sw takes (wider ones are aligned inside k_matesw)
+
 // per pair: copy both lists into their (larger) slots; list the pair for k_matesw if any anchor has an orientation left
 __global__ void k_pe_copy(PairLaunch a)
 {
@@ -118,14 +149,29 @@ __global__ void k_pe_copy(PairLaunch a)
 		a.pe_n[r] = n;
 		const int m = r ^ 1;
 		const DevReg *ma = a.regs + a.reg_base[m];
-		for (int j = 0; j < a.nb[r] && !need; ++j) need = skip_mask_seq(a, src[j].rb, ma, a.reg_n[m]) != 15;
+		const int l_ms = (int)(a.off[m + 1] - a.off[m]);
+		for (int j = 0; j < a.nb[r]; ++j) {
+			const int sk = skip_mask_seq(a, src[j].rb, ma, a.reg_n[m]);
+			if (sk == 15) continue;
+			need = true;
+			// the alignments this anchor asks for against the unrescued list can be done ahead, in parallel (k_matesw_sw)
+			if (l_ms * a.opt.a < 250)
+				for (int o = 0; o < 4; ++o) {
+					int64_t rb, re;
+					if ((sk >> o & 1) || !ms_window(a, src[j], o, l_ms, rb, re) || re - rb > SW_TW) continue;
+					const int slot = (int)a.sw_base[r] + 4 * j + o;
+					a.sw_res[slot].state = 1;
+					a.sw_tasks[atomicAdd(a.sw_n, 1)] = slot;
+					a.sw_info[slot] = make_int2(r, j << 2 | o);
+				}
+		}
 	}
 	if (need) a.resc_list[atomicAdd(a.resc_n, 1)] = p;
 }
 
 // ---------------------------------------------------------------------------------------------------- mem_matesw
 constexpr int MS_MAXQ = BWAHIP_MAX_READ_LEN;
-constexpr int MS_LIST = 96;                                  // regions of a mate list worked on in LDS
+constexpr int MS_LIST = 224;                                 // regions of a mate list worked on in LDS
 
 struct MsLds {
 	uint8_t *q;                                                  // mate read (or its reverse complement), codes
@@ -143,7 +189,7 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 	if (n <= 1) return n;
 	for (int i = l; i < n; i += 64) { keys[i].k64 = L[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 	wsync();
-	if (n < 64 || !wave_rank_sort(RegSort{keys, 0}, n, idx, l)) {
+	if (n < 8 || !wave_rank_sort(RegSort{keys, 0}, n, idx, l)) {
 		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, stk, &bad); if (bad) atomicExch(err, 40 + bad); }
 	}
 	wsync();
@@ -181,7 +227,7 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 	n = m;
 	for (int i = l; i < n; i += 64) { L[i] = tmp[i]; keys[i].k64 = tmp[i].rb; keys[i].score = tmp[i].score; keys[i].qb = tmp[i].qb; idx[i] = i; }
 	wsync();
-	if (n < 64 || !wave_rank_sort(RegSort{keys, 1}, n, idx, l)) {
+	if (n < 8 || !wave_rank_sort(RegSort{keys, 1}, n, idx, l)) {
 		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, stk, &bad); if (bad) atomicExch(err, 50 + bad); }
 	}
 	wsync();
@@ -203,8 +249,8 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 // mem_matesw (bwamem_pair.c:137-206): anchor `an` (a region of one end), mate read r_m (length l_ms), mate list L (n_ma).
 // P = 16: byte kernel (l_ms * a < 250), P = 8: word kernel.  Returns the new length of the mate list.
 template <int P>
-__device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int r_m, int l_ms, DevReg *L, int n_ma, DevReg *tmp, RegKey *keys, int *idx,
-                      const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new)
+__device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int slot0, int r_m, int l_ms, DevReg *L, int n_ma, DevReg *tmp, RegKey *keys, int *idx,
+                      const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new, unsigned long long &n_inline)
 {
 	const DevOpt &opt = a.opt;
 	const DevIndex &ix = a.ix;
@@ -226,51 +272,38 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 	int n = 0;
 	for (int r = 0; r < 4; ++r) {
 		if (skip >> r & 1) continue;
-		const int is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);
+		const int is_rev = (r >> 1) != (r & 1);
 		int64_t rb, re;
-		if (!is_rev) {
-			rb = is_larger ? an.rb + a.pes[r].low : an.rb - a.pes[r].high;
-			re = (is_larger ? an.rb + a.pes[r].high : an.rb - a.pes[r].low) + l_ms;
-		} else {
-			rb = (is_larger ? an.rb + a.pes[r].low : an.rb - a.pes[r].high) - l_ms;
-			re = is_larger ? an.rb + a.pes[r].high : an.rb - a.pes[r].low;
-		}
-		if (rb < 0) rb = 0;
-		if (re > l_pac << 1) re = l_pac << 1;
-		int rid = -1;
-		if (rb < re) {                                            // bns_fetch_seq (bntseq.c:426): clamp to the contig holding the middle
-			const int64_t mid = (rb + re) >> 1;
-			const bool mrev = mid >= l_pac;
-			rid = dev_pos2rid(ix, mrev ? (l_pac << 1) - 1 - mid : mid);
-			int64_t far_beg = ix.anns[rid].offset, far_end = far_beg + ix.anns[rid].len;
-			if (mrev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
-			rb = rb > far_beg ? rb : far_beg;
-			re = re < far_end ? re : far_end;
-		}
-		if (an.rid == rid && re - rb >= opt.min_seed_len) {
+		if (ms_window(a, an, r, l_ms, rb, re)) {
 			const unsigned long long tk0 = wall_clock64();
 			const int tlen = (int)(re - rb);
-			uint8_t *s_t = tlen <= m.tw_cap ? m.tw : slab;             // reference window: LDS, or this workgroup's global scratch when too wide
-			__syncthreads();
-			for (int i = l; i < tlen; i += 64) s_t[i] = (uint8_t)ref_base(ix, rb + i);
-			if (is_rev) for (int i = l; i < l_ms; i += 64) { const uint8_t c = ms[i]; m.q[l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
-			else for (int i = l; i < l_ms; i += 64) m.q[i] = ms[i];
-			wsync();
-			const unsigned long long tk1 = wall_clock64();
-			const int xtra = ssw::XSUBO | ssw::XSTART | (P == 16 ? ssw::XBYTE : 0) | (opt.min_seed_len * opt.a);
 			ssw::Res aln = { 0, -1, -1, -1, -1, -1, -1 };
-			if (l < P) {                                          // one group of the wavefront runs the alignment
-				const int cells = (l_ms + P - 1) / P * P;
-				ssw::Work w;
-				w.prof = m.prof; w.H0 = m.h; w.H1 = m.h + cells; w.E = m.h + 2 * cells; w.Hmax = m.h + 3 * cells;
-				w.colmax = tlen <= m.tw_cap ? m.cm : reinterpret_cast<uint16_t*>(slab + ((size_t)tlen + 63) / 64 * 64);
-				// byte kernel: at most 16 segments (249 bases); 10 covers reads up to 160 bases
-				if (P == 16 && l_ms <= 160) aln = ssw::align2<P, 10>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
-				else if (P == 16) aln = ssw::align2<P, 16>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
-				else aln = ssw::align2<P>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+			const SwRes pre = P == 16 ? a.sw_res[slot0 + r] : SwRes{ 0, 0, 0, 0, 0, 0, 0, 0 };
+			const unsigned long long tk1 = wall_clock64();
+			if (pre.state == 2) {                                     // done ahead by k_matesw_sw (same anchor, orientation, window)
+				aln.score = pre.score; aln.te = pre.te; aln.qe = pre.qe; aln.score2 = pre.score2; aln.te2 = pre.te2; aln.tb = pre.tb; aln.qb = pre.qb;
+			} else {
+				uint8_t *s_t = tlen <= m.tw_cap ? m.tw : slab;             // reference window: LDS, or this workgroup's global scratch when too wide
+				__syncthreads();
+				for (int i = l; i < tlen; i += 64) s_t[i] = (uint8_t)ref_base(ix, rb + i);
+				if (is_rev) for (int i = l; i < l_ms; i += 64) { const uint8_t c = ms[i]; m.q[l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
+				else for (int i = l; i < l_ms; i += 64) m.q[i] = ms[i];
+				wsync();
+				const int xtra = ssw::XSUBO | ssw::XSTART | (P == 16 ? ssw::XBYTE : 0) | (opt.min_seed_len * opt.a);
+				if (l < P) {                                          // one group of the wavefront runs the alignment
+					const int cells = (l_ms + P - 1) / P * P;
+					ssw::Work w;
+					w.prof = m.prof; w.H0 = m.h; w.H1 = m.h + cells; w.E = m.h + 2 * cells; w.Hmax = m.h + 3 * cells;
+					w.colmax = tlen <= m.tw_cap ? m.cm : reinterpret_cast<uint16_t*>(slab + ((size_t)tlen + 63) / 64 * 64);
+					// byte kernel: at most 16 segments (249 bases); 10 covers reads up to 160 bases
+					if (P == 16 && l_ms <= 160) aln = ssw::align2<P, 10>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+					else if (P == 16) aln = ssw::align2<P, 16>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+					else aln = ssw::align2<P>(w, l, l_ms, m.q, 1, tlen, s_t, 1, m.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+				}
+				aln.score = __shfl(aln.score, 0); aln.te = __shfl(aln.te, 0); aln.qe = __shfl(aln.qe, 0); aln.score2 = __shfl(aln.score2, 0);
+				aln.tb = __shfl(aln.tb, 0); aln.qb = __shfl(aln.qb, 0);
+				++n_inline;
 			}
-			aln.score = __shfl(aln.score, 0); aln.te = __shfl(aln.te, 0); aln.qe = __shfl(aln.qe, 0); aln.score2 = __shfl(aln.score2, 0);
-			aln.tb = __shfl(aln.tb, 0); aln.qb = __shfl(aln.qb, 0);
 			++n_sw;
 			const unsigned long long tk2 = wall_clock64();
 			if (l == 0) { atomicAdd(&a.counters[4], tk1 - tk0); atomicAdd(&a.counters[5], tk2 - tk1); }
@@ -311,6 +344,45 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 	return n_ma;
 }
 
+// The alignments k_pe_copy queued: one per 16-lane group, four per wavefront, byte kernel, cells in registers.  A single
+// alignment is a chain of ~1 500 dependent cycles per reference base; what this kernel buys is that the (up to dozens of)
+// alignments of one pair, which mem_matesw runs one after the other, proceed side by side.
+__global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
+{
+	__shared__ int8_t s_mat[32];
+	__shared__ uint8_t s_tw[4][SW_TW];
+	__shared__ uint16_t s_cm[4][SW_TW];
+	__shared__ uint8_t s_q[4][256];
+	__shared__ int8_t s_prof[4][5 * 256];
+	const int lane_ = lane(), g = lane_ >> 4, gl = lane_ & 15;
+	if (lane_ < 25) s_mat[lane_] = a.opt.mat[lane_];
+	__syncthreads();
+	const int n_tasks = *a.sw_n;
+	const int t = (int)blockIdx.x * 4 + g;
+	if (t >= n_tasks) return;
+	const int slot = a.sw_tasks[t];
+	const int2 info = a.sw_info[slot];
+	const int r = info.x, j = info.y >> 2, o = info.y & 3, rm = r ^ 1;
+	const DevReg an = a.regs[a.reg_base[r] + j];
+	const int l_ms = (int)(a.off[rm + 1] - a.off[rm]);
+	const uint8_t *ms = a.seq + a.off[rm];
+	int64_t rb, re;
+	ms_window(a, an, o, l_ms, rb, re);                            // eligibility was established by k_pe_copy
+	const int tlen = (int)(re - rb);
+	const int is_rev = (o >> 1) != (o & 1);
+	for (int i = gl; i < tlen; i += 16) s_tw[g][i] = (uint8_t)ref_base(a.ix, rb + i);
+	if (is_rev) for (int i = gl; i < l_ms; i += 16) { const uint8_t c = ms[i]; s_q[g][l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
+	else for (int i = gl; i < l_ms; i += 16) s_q[g][i] = ms[i];
+	__threadfence_block();
+	ssw::Work w;
+	w.prof = s_prof[g]; w.H0 = w.H1 = w.E = w.Hmax = nullptr; w.colmax = s_cm[g];
+	const int xtra = ssw::XSUBO | ssw::XSTART | ssw::XBYTE | (a.opt.min_seed_len * a.opt.a);
+	ssw::Res aln;
+	if (l_ms <= 160) aln = ssw::align2<16, 10>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
+	else aln = ssw::align2<16, 16>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
+	if (gl == 0) { SwRes o_ = { 2, aln.score, aln.te, aln.qe, aln.score2, aln.te2, aln.tb, aln.qb }; a.sw_res[slot] = o_; }
+}
+
 template <int P>
 __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 {
@@ -332,7 +404,7 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 	if (l < 25) s_mat[l] = a.opt.mat[l];
 	__syncthreads();
 	uint8_t *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
-	unsigned long long n_sw = 0, n_new = 0, max_sw = 0;
+	unsigned long long n_sw = 0, n_new = 0, max_sw = 0, n_inline = 0;
 	const int n_resc = *a.resc_n;
 	for (int it = (int)blockIdx.x; it < n_resc; it += (int)gridDim.x) {
 		const int p = a.resc_list[it];
@@ -358,14 +430,14 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 				wsync();
 				const MsLds m = { s_q, s_mat, s_prof, s_h, s_keys, s_idx, s_stk, s_tw, 4096, s_cm };
 				for (int j = 0; j < a.nb[r]; ++j)
-					n_list[i ^ 1] = matesw<P>(a, snap[j], rm, l_ms, s_list, n_list[i ^ 1], s_tmp, s_keys, s_idx, m, slab, l, n_sw, n_new);
+					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, s_list, n_list[i ^ 1], s_tmp, s_keys, s_idx, m, slab, l, n_sw, n_new, n_inline);
 			} else {
 				DevReg *tmp = a.pe_tmp + a.pe_base[rm];
 				RegKey *keys = reinterpret_cast<RegKey*>(a.pe_keys) + a.pe_base[rm];
 				int *idx = a.pe_idx + 2 * a.pe_base[rm];
 				const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk, s_tw, 4096, s_cm };
 				for (int j = 0; j < a.nb[r]; ++j)
-					n_list[i ^ 1] = matesw<P>(a, snap[j], rm, l_ms, G, n_list[i ^ 1], tmp, keys, idx, m, slab, l, n_sw, n_new);
+					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, G, n_list[i ^ 1], tmp, keys, idx, m, slab, l, n_sw, n_new, n_inline);
 			}
 			if (in_lds) { wsync(); for (int k = l; k < n_list[i ^ 1]; k += 64) G[k] = s_list[k]; wsync(); }
 		}
@@ -379,7 +451,7 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 		if (l == 0) atomicMax(&a.counters[7], wall_clock64() - tp0);
 		__syncthreads();
 	}
-	if (l == 0) { if (n_sw) { atomicAdd(&a.counters[0], n_sw); atomicAdd(&a.counters[1], n_new); atomicMax(&a.counters[2], max_sw); } if (blockIdx.x == 0) atomicMax(&a.counters[3], (unsigned long long)n_resc); }
+	if (l == 0) { if (n_sw) { atomicAdd(&a.counters[0], n_sw); atomicAdd(&a.counters[1], n_new); atomicMax(&a.counters[2], max_sw); atomicAdd(&a.counters[8], n_inline); } if (blockIdx.x == 0) atomicMax(&a.counters[3], (unsigned long long)n_resc); }
 }
 
 // ---------------------------------------------------------------------------------------------------- mem_pair + mem_sam_pe decisions
@@ -628,6 +700,12 @@ int launch_matesw(const PairLaunch &a, int grid, hipStream_t st)
 	if (grid <= 0) return 0;
 	hipLaunchKernelGGL(k_matesw<16>, dim3(grid), dim3(64), 0, st, a);   // mates under 250 bases: byte kernel
 	hipLaunchKernelGGL(k_matesw<8>, dim3(grid), dim3(64), 0, st, a);    // longer mates: word kernel (after the byte one: a pair may need both)
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st)
+{
+	if (n_tasks <= 0) return 0;
+	hipLaunchKernelGGL(k_matesw_sw, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 int launch_pair(const PairLaunch &a, hipStream_t st)
