@@ -48,6 +48,11 @@ def usable_cpus():
 
 
 def main():
+    # exactly ONE line on stdout: libraries (RCCL prints a version banner) write there too, so fd 1 is pointed at stderr for the
+    # whole run and the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -316,7 +321,7 @@ def main():
                 out["parity_checked"] = f"{n_s} reads: SAM of bwahip_process_seqs vs SAM of oracle/_ref/bwaref (the reference's own mem_process_seqs), byte for byte"
                 if not parity_ok:
                     log("PARITY FAILURE: GPU SAM differs from the reference CPU path's SAM on the bench workload")
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if parity_ok is False:
             if world > 1:
                 dist.destroy_process_group()

@@ -216,6 +216,7 @@ struct FinLaunch {
 	// alignment tasks
 	const int64_t *task_base;                    // exclusive scan of task_n
 	int2 *tasks;                                 // (read, region index)
+	int *fast_list, *dp_list, *list_n;           // task ids without / with a DP (k_cigar<true> / <false>); list_n[2]: their lengths
 	int *aln_of_reg;                             // per region slot: task id or -1
 	DevAln *alns;
 	uint8_t *pool; unsigned long long *pool_head; unsigned long long pool_cap;   // CIGAR / MD text: bump allocation
@@ -232,7 +233,7 @@ struct FinLaunch {
 };
 int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st);
 int launch_task_fill(const FinLaunch &a, hipStream_t st);
-int launch_cigar(const FinLaunch &a, int64_t n_tasks, hipStream_t st);
+int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st);   // the tasks k_cigar listed in redo_list; big_z: grid slabs of cigar_big_slab_bytes()
 size_t cigar_big_slab_bytes();
 int launch_sam(const FinLaunch &a, bool write, hipStream_t st);

@@ -93,6 +93,7 @@ struct bwahip_ctx {
 	DevBuf d_hist, d_pair_tab, d_nb, d_pe_cap, d_pe_base, d_pe_regs, d_pe_n, d_pe_tmp, d_pe_keys, d_pe_idx, d_resc, d_ms_slab, d_pe_read, d_sw_cnt, d_sw_base, d_sw_res, d_sw_tasks, d_sw_info;   // paired-end stages
 	bwahip_pestat_t last_pes[4];         // insert-size statistics of the last paired-end batch
 	unsigned long long last_pe_counters[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // mate-rescue alignments run / regions added / most per pair / pairs rescued
+	DevBuf d_task_lists;                 // k_cigar's two work lists (no-DP tasks, DP tasks)
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
 	HostBuf h_stage, h_sam;               // pinned staging: batch text in, SAM text out
 	int64_t total_tasks = 0, total_sam = 0;

@@ -210,16 +210,21 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->total_tasks = T;
 	const size_t Tn = (size_t)(T ? T : 1);
-	if ((rc = c->d_tasks.ensure(Tn * 8)) || (rc = c->d_alns.ensure(Tn * sizeof(DevAln))) || (rc = c->d_fredo.ensure((Tn + 4) * 4))) return rc;
+	if ((rc = c->d_tasks.ensure(Tn * 8)) || (rc = c->d_alns.ensure(Tn * sizeof(DevAln))) || (rc = c->d_fredo.ensure((Tn + 4) * 4)) || (rc = c->d_task_lists.ensure(2 * Tn * 4))) return rc;
 	f.tasks = c->d_tasks.as<int2>(); f.alns = c->d_alns.as<DevAln>(); f.redo_list = c->d_fredo.as<int>();
+	f.fast_list = c->d_task_lists.as<int>(); f.dp_list = f.fast_list + Tn; f.list_n = (int*)(pool_head + 15);
 	if ((rc = launch_task_fill(f, c->stream))) return rc;
-	size_t want_pool = std::max(c->pool_cap, Tn * 96 + (size_t)(16 << 20));
+	int n_list[2] = { 0, 0 };
+	HIP_TRY(hipMemcpyAsync(n_list, f.list_n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	size_t want_pool = std::max(c->pool_cap, Tn * 64 + Tn * 32 + (size_t)(16 << 20));   // 64-byte slot per task + a shared tail for long texts
 	for (int attempt = 0;; ++attempt) {
 		if ((rc = c->d_pool.ensure(want_pool))) return rc;
 		c->pool_cap = want_pool;
 		f.pool = c->d_pool.as<uint8_t>(); f.pool_cap = want_pool;
-		HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 128, c->stream));
-		if ((rc = launch_cigar(f, T, c->stream))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 120, c->stream));   // pool head, redo count, error; the task-list lengths at +120 stay
+		{ const unsigned long long head0 = (unsigned long long)Tn * 64; HIP_TRY(hipMemcpyAsync(c->d_fmisc.p, &head0, 8, hipMemcpyHostToDevice, c->stream)); }   // the shared tail starts behind the slots
+		if ((rc = launch_cigar(f, n_list[0], n_list[1], c->stream, c->stream2, c->ev_fork, c->ev_join))) return rc;
 		int h[6] = { 0 };
 		HIP_TRY(hipMemcpyAsync(h, c->d_fmisc.p, 24, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));

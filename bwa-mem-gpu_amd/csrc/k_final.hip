@@ -183,17 +183,62 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 	if (l == 0) { a.task_n[r] = n_task; a.rec_n[r] = n_rec; }
 }
 
-// the (read, region) pair of every alignment task, in read order then region order
-__global__ void k_task_fill(FinLaunch a)
+__device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q, int r)   // bwamem.c:799
 {
-	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= a.n_reads) return;
-	const int n = a.freg_n[r];
-	const int64_t rb0 = a.reg_base[r];
-	int64_t t = a.task_base[r];
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	int w = (int)(((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.));
+	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
+	if (w < d) w = d;
+	return w;
+}
+// the band mem_reg2aln starts with (bwamem.c:1118-1122); 0 with equal lengths means bwa_gen_cigar2 takes its no-DP shortcut
+__device__ __forceinline__ int first_band(const DevOpt &opt, const FinReg &ar)
+{
+	const int lq = ar.qe - ar.qb, rlen = (int)(ar.re - ar.rb);
+	const int tmp = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_del, opt.e_del);
+	int w2 = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+	w2 = w2 > tmp ? w2 : tmp;
+	if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+	return w2;
+}
+
+// the (read, region) pair of every alignment task, in read order then region order; and the two work lists of k_cigar: tasks
+// that need no DP (equal lengths, band 0: a handful of mismatches at most -- four out of five at 1 % error) and the rest.
+// List positions come from one block-wide scan and one atomic per block and list (1.2 M tasks on two counters otherwise).
+__global__ __launch_bounds__(256) void k_task_fill(FinLaunch a)
+{
+	__shared__ int s_cnt[2][256];
+	__shared__ int s_base[2];
+	const int r = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
+	int n_fast = 0, n_dp = 0;
+	const bool live = r < a.n_reads;
+	const int n = live ? a.freg_n[r] : 0;
+	const int64_t rb0 = live ? a.reg_base[r] : 0;
+	int64_t t = live ? a.task_base[r] : 0;
 	for (int i = 0; i < n; ++i) {
-		if (a.need[rb0 + i]) { a.tasks[t] = make_int2(r, i); a.aln_of_reg[rb0 + i] = (int)t; ++t; }
-		else a.aln_of_reg[rb0 + i] = -1;
+		if (a.need[rb0 + i]) {
+			a.tasks[t] = make_int2(r, i); a.aln_of_reg[rb0 + i] = (int)t; ++t;
+			const FinReg ar = a.fregs[rb0 + i];
+			if (ar.qe - ar.qb == (int)(ar.re - ar.rb) && first_band(a.opt, ar) == 0) ++n_fast; else ++n_dp;
+		} else a.aln_of_reg[rb0 + i] = -1;
+	}
+	s_cnt[0][tid] = n_fast; s_cnt[1][tid] = n_dp;
+	__syncthreads();
+	for (int d = 1; d < 256; d <<= 1) {                          // inclusive scans of both counts
+		const int v0 = tid >= d ? s_cnt[0][tid - d] : 0, v1 = tid >= d ? s_cnt[1][tid - d] : 0;
+		__syncthreads();
+		s_cnt[0][tid] += v0; s_cnt[1][tid] += v1;
+		__syncthreads();
+	}
+	if (tid == 255) { s_base[0] = atomicAdd(&a.list_n[0], s_cnt[0][255]); s_base[1] = atomicAdd(&a.list_n[1], s_cnt[1][255]); }
+	__syncthreads();
+	int pf = s_base[0] + s_cnt[0][tid] - n_fast, pd = s_base[1] + s_cnt[1][tid] - n_dp;
+	t = live ? a.task_base[r] : 0;
+	for (int i = 0; i < n; ++i) {
+		if (!a.need[rb0 + i]) continue;
+		const FinReg ar = a.fregs[rb0 + i];
+		if (ar.qe - ar.qb == (int)(ar.re - ar.rb) && first_band(a.opt, ar) == 0) a.fast_list[pf++] = (int)t; else a.dp_list[pd++] = (int)t;
+		++t;
 	}
 }
 
@@ -205,6 +250,7 @@ constexpr int CG_MAXT = 1536;                                // reference span o
 constexpr int CG_ZLDS = 12288;                               // backtrack matrix bytes kept in LDS
 constexpr int CG_MAXC = 512;                                 // CIGAR operations staged in LDS
 constexpr int CG_MAXMD = 1024;                               // MD bytes staged in LDS
+constexpr unsigned long long CG_SLOT = 64;                   // bytes of pool every task owns (see reg2aln)
 constexpr int CG_BIG_T = 8192;                               // k_cigar_big: reference span / matrix rows in its global slab
 constexpr size_t CG_BIG_Z = (size_t)(CG_MAXQ + 1) * CG_BIG_T;
 
@@ -283,14 +329,6 @@ __device__ int wave_global_trace(const Sw &sw, const uint8_t *q, int qs, int qle
 	return wmax(score);
 }
 
-__device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q, int r)   // bwamem.c:799
-{
-	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
-	int w = (int)(((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.));
-	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
-	if (w < d) w = d;
-	return w;
-}
 
 // decimal digits of a non-negative integer into dst; returns the count
 __device__ __forceinline__ int put_uint(uint8_t *dst, unsigned v)
@@ -305,8 +343,8 @@ struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; }
 
 // One task: region `ar` of read r -> DevAln (+ CIGAR words and MD text appended to the pool).  BIG: window / matrix in the
 // workgroup's global slab.  Returns false when the task does not fit this variant (caller lists it for k_cigar_big).
-template <bool BIG>
-__device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, const CigarLds &m, int t_cap, size_t z_cap, DevAln *out)
+template <bool BIG, bool NODP = false>
+__device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, long long task_id, const CigarLds &m, int t_cap, size_t z_cap, DevAln *out)
 {
 	const int l = lane();
 	const DevOpt &opt = a.opt;
@@ -343,7 +381,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 	do {                                                         // bwamem.c:1124-1132
 		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
 		// ---- bwa_gen_cigar2 (bwa.c:281-307)
-		if (lq == rlen && w2 == 0) {
+		if (NODP || (lq == rlen && w2 == 0)) {                    // NODP: the caller established that the shortcut is taken (k_task_fill)
 			int part = 0;
 			for (int i = l; i < lq; i += 64) part += m.mat[tp[i * ts] * 5 + qp[i * qs]];
 			score = wsum(part);
@@ -469,11 +507,15 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 	al.is_alt = (uint32_t)ar.is_alt; al.alt_sc = ar.alt_sc;
 	al.n_cigar = n_out; al.md_len = md_len; al.pad = 0; al.pad2 = 0;
 	// ---- CIGAR words + MD text into the pool
+	// every task owns a 64-byte slot at the start of the pool (CIGAR words + MD of an ordinary hit fit); only longer texts take
+	// space from the shared tail through an atomic (1.2 M tasks bumping one counter cost more than everything else here)
 	const unsigned long long bytes = ((unsigned long long)n_out * 4 + (unsigned long long)md_len + 7) & ~7ull;
-	unsigned long long at = 0;
-	if (l == 0) at = atomicAdd(a.pool_head, bytes);
-	at = (unsigned long long)__shfl((long long)at, 0);
-	if (at + bytes > a.pool_cap) { if (l == 0) atomicExch(a.err, 5); return true; }   // pool exhausted: the host re-runs the stage with a larger one
+	unsigned long long at = (unsigned long long)task_id * CG_SLOT;
+	if (bytes > CG_SLOT) {
+		if (l == 0) at = atomicAdd(a.pool_head, bytes);
+		at = (unsigned long long)__shfl((long long)at, 0);
+		if (at + bytes > a.pool_cap) { if (l == 0) atomicExch(a.err, 5); return true; }   // pool exhausted: the host re-runs the stage with a larger one
+	}
 	uint32_t *dc = reinterpret_cast<uint32_t*>(a.pool + at);
 	const int lead = clip5 ? 1 : 0;
 	if (l == 0) { if (clip5) dc[0] = (uint32_t)clip5 << 4 | 3; if (clip3) dc[n_out - 1] = (uint32_t)clip3 << 4 | 3; }
@@ -485,17 +527,20 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 	return true;
 }
 
-__global__ __launch_bounds__(64) void k_cigar(FinLaunch a, long long n_tasks)
+// FAST: the tasks of fast_list (no DP: no backtrack matrix, one CIGAR operation) with a fifth of the LDS, so that several
+// times more of them are in flight -- the kernel waits on chains of dependent global loads, not on arithmetic
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
 {
 	__shared__ uint8_t s_q[CG_MAXQ + 8];
 	__shared__ uint8_t s_t[CG_MAXT + 8];
-	__shared__ uint8_t s_z[CG_ZLDS];
-	__shared__ uint32_t s_cig[CG_MAXC];
+	__shared__ uint8_t s_z[FAST ? 16 : CG_ZLDS];
+	__shared__ uint32_t s_cig[FAST ? 8 : CG_MAXC];
 	__shared__ uint8_t s_md[CG_MAXMD];
 	__shared__ int8_t s_mat[32];
-	const long long t = blockIdx.x;
 	const int l = lane();
-	if (t >= n_tasks) return;
+	if ((int)blockIdx.x >= n_list) return;
+	const long long t = FAST ? a.fast_list[blockIdx.x] : a.dp_list[blockIdx.x];
 	const int2 tk = a.tasks[t];
 	const int r = tk.x;
 	const int l_query = (int)(a.off[r + 1] - a.off[r]);
@@ -505,7 +550,7 @@ __global__ __launch_bounds__(64) void k_cigar(FinLaunch a, long long n_tasks)
 	__syncthreads();
 	const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
 	const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat };
-	if (!reg2aln<false>(a, ar, r, m, CG_MAXT, CG_ZLDS, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
+	if (!reg2aln<false, FAST>(a, ar, r, t, m, CG_MAXT, FAST ? 0 : CG_ZLDS, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
 }
 
 // tasks whose reference span, backtrack matrix, CIGAR or MD did not fit LDS: the same code on this workgroup's global slab
@@ -530,7 +575,7 @@ __global__ __launch_bounds__(64) void k_cigar_big(FinLaunch a)
 		__syncthreads();
 		const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
 		const CigarLds m = { s_q, slab + CG_BIG_Z, slab, s_cig, s_md, s_mat };
-		if (!reg2aln<true>(a, ar, r, m, CG_BIG_T, CG_BIG_Z, a.alns + t) && l == 0) { atomicExch(a.err, 6); atomicExch(a.err + 1, r); }
+		if (!reg2aln<true>(a, ar, r, t, m, CG_BIG_T, CG_BIG_Z, a.alns + t) && l == 0) { atomicExch(a.err, 6); atomicExch(a.err + 1, r); }
 	}
 }
 
@@ -553,10 +598,14 @@ int launch_task_fill(const FinLaunch &a, hipStream_t st)
 
 size_t cigar_big_slab_bytes() { return CG_BIG_Z + CG_BIG_T + 64; }
 
-int launch_cigar(const FinLaunch &a, int64_t n_tasks, hipStream_t st)
+// the two lists run side by side (st2 forks from st and joins it again): the no-DP tasks wait on memory, the DP tasks compute
+int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
 {
-	if (n_tasks <= 0) return 0;
-	hipLaunchKernelGGL(k_cigar, dim3((unsigned)n_tasks), dim3(64), 0, st, a, (long long)n_tasks);
+	const bool both = n_fast > 0 && n_dp > 0;
+	if (both && (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess)) return BWAHIP_ENODEV;
+	if (n_dp > 0) hipLaunchKernelGGL(k_cigar<false>, dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
+	if (n_fast > 0) hipLaunchKernelGGL(k_cigar<true>, dim3((unsigned)n_fast), dim3(64), 0, both ? st2 : st, a, n_fast);
+	if (both && (hipEventRecord(join, st2) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess)) return BWAHIP_ENODEV;
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
