@@ -233,7 +233,7 @@ struct FinLaunch {
 };
 int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st);
 int launch_task_fill(const FinLaunch &a, hipStream_t st);
-int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
+int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st);   // the tasks k_cigar listed in redo_list; big_z: grid slabs of cigar_big_slab_bytes()
 size_t cigar_big_slab_bytes();
 int launch_sam(const FinLaunch &a, bool write, hipStream_t st);

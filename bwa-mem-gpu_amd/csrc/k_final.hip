@@ -343,7 +343,7 @@ struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; }
 
 // One task: region `ar` of read r -> DevAln (+ CIGAR words and MD text appended to the pool).  BIG: window / matrix in the
 // workgroup's global slab.  Returns false when the task does not fit this variant (caller lists it for k_cigar_big).
-template <bool BIG, bool NODP = false>
+template <bool BIG, bool NODP = false, int CPLMAX = 11>
 __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, int r, long long task_id, const CigarLds &m, int t_cap, size_t z_cap, DevAln *out)
 {
 	const int l = lane();
@@ -400,11 +400,13 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
 			if ((size_t)n_col * (size_t)rlen > z_cap) { fits = false; break; }
 			__syncthreads();
+			// the fewest columns per lane that hold the query; CPLMAX (from the longest read of the batch) bounds what is
+			// compiled in, and with it the registers of the kernel
 			if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else if (lq < 128) score = wave_global_trace<2>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else if (lq < 192) score = wave_global_trace<3>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else if (lq < 256) score = wave_global_trace<4>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else score = wave_global_trace<11>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (CPLMAX <= 2 || lq < 128) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (CPLMAX <= 3 || lq < 192) score = wave_global_trace<(CPLMAX < 3 ? CPLMAX : 3)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (CPLMAX <= 4 || lq < 256) score = wave_global_trace<(CPLMAX < 4 ? CPLMAX : 4)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else score = wave_global_trace<CPLMAX>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			wsync();
 			// ---- backtrack (ksw.c:586-603); operations are produced last to first and reversed afterwards
 			int nc = 0;
@@ -529,7 +531,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 
 // FAST: the tasks of fast_list (no DP: no backtrack matrix, one CIGAR operation) with a fifth of the LDS, so that several
 // times more of them are in flight -- the kernel waits on chains of dependent global loads, not on arithmetic
-template <bool FAST>
+template <bool FAST, int CPLMAX>
 __global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
 {
 	__shared__ uint8_t s_q[CG_MAXQ + 8];
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
 	__syncthreads();
 	const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
 	const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat };
-	if (!reg2aln<false, FAST>(a, ar, r, t, m, CG_MAXT, FAST ? 0 : CG_ZLDS, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
+	if (!reg2aln<false, FAST, CPLMAX>(a, ar, r, t, m, CG_MAXT, FAST ? 0 : CG_ZLDS, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
 }
 
 // tasks whose reference span, backtrack matrix, CIGAR or MD did not fit LDS: the same code on this workgroup's global slab
@@ -599,12 +601,16 @@ int launch_task_fill(const FinLaunch &a, hipStream_t st)
 size_t cigar_big_slab_bytes() { return CG_BIG_Z + CG_BIG_T + 64; }
 
 // the two lists run side by side (st2 forks from st and joins it again): the no-DP tasks wait on memory, the DP tasks compute
-int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
+int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
 {
 	const bool both = n_fast > 0 && n_dp > 0;
 	if (both && (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess)) return BWAHIP_ENODEV;
-	if (n_dp > 0) hipLaunchKernelGGL(k_cigar<false>, dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
-	if (n_fast > 0) hipLaunchKernelGGL(k_cigar<true>, dim3((unsigned)n_fast), dim3(64), 0, both ? st2 : st, a, n_fast);
+	if (n_dp > 0) {                                             // query columns of the longest read over 64 lanes
+		if (max_len < 64 * 3) hipLaunchKernelGGL((k_cigar<false, 3>), dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
+		else if (max_len < 64 * 5) hipLaunchKernelGGL((k_cigar<false, 5>), dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
+		else hipLaunchKernelGGL((k_cigar<false, 11>), dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
+	}
+	if (n_fast > 0) hipLaunchKernelGGL((k_cigar<true, 1>), dim3((unsigned)n_fast), dim3(64), 0, both ? st2 : st, a, n_fast);
 	if (both && (hipEventRecord(join, st2) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess)) return BWAHIP_ENODEV;
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
