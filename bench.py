@@ -273,6 +273,7 @@ def main():
             "config": {"workload": f"{kind}, {args.sub_ppm / 10000:g}% substitutions, per GPU and step, in batches of {args.batch} reads (-K {args.batch * rl}) vs "
                                    f"{args.genome_mbp} Mbp synthetic genome with repeat families (GRCh38 not available offline); "
                                    f"BASELINE configs[{2 if pe else 1}] shape",
+                       "launch_workload": f"one batch of {args.batch} {'PE' if pe else 'SE'} reads of {rl} bp, {args.sub_ppm / 10000:g}% substitutions vs {args.genome_mbp} Mbp synthetic genome",
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "read_len": rl, "paired": pe, "genome_mbp": args.genome_mbp,
                        "stages": ctx.stage_names(),
                        "output": ctx.output_description(pe),
@@ -294,10 +295,11 @@ def main():
             out["e2e"] = {"what": "bwahip_process_seqs: host bseq1_t arrays in (ASCII reads, names, qualities) -> seqs[i].sam text out, one batch per GPU, PCIe and host work included",
                           "reads": e2e["reads"], "seconds": round(e2e["seconds"], 4), "host_threads_per_gpu": e2e["host_threads_per_gpu"]}
         # HBM traffic of the same kernel from the committed PMC passes of this very command (counters cannot be read from
-        # inside the process); quoted only when workload AND kernel sources are the ones the counters were collected on
+        # inside the process); quoted only when the per-launch workload (one batch) AND the kernel sources are the ones the
+        # counters were collected on
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == out["config"]["workload"] and pt.get("kernel_src_sha256") == kernel_src_sha():
+            if pt.get("launch_workload") == out["config"]["launch_workload"] and pt.get("kernel_src_sha256") == kernel_src_sha():
                 out["roofline"]["traffic"] = int(pt["fetch_bytes_per_launch"] + pt["write_bytes_per_launch"])
                 out["roofline"]["traffic_source"] = pt["source"]
         except (OSError, ValueError, KeyError):
@@ -400,7 +402,7 @@ def cpu_baseline(tp, prefix, sample, pe, cpus, workdir):
         secs2, _ = run(["-Z"], subprocess.DEVNULL)
         if secs2:
             res["hot_path_value"] = round(n / secs2, 1)
-            res["hot_path_sample"] = f"the same reads through kt_for(worker1) only (mem_align1_core per read, bwamem.c:1232) in {secs2:.2f}s: like-for-like with `value`"
+            res["hot_path_sample"] = f"the same reads through kt_for(worker1) only (mem_align1_core per read, bwamem.c:1232) in {secs2:.2f}s (the share of the CPU path that mem_align1_core is; `value` covers all of mem_process_seqs, like `cpu_baseline.value`)"
     return res, sam_path
 
 

@@ -213,6 +213,7 @@ static int main_mem(int argc, char **argv)
 	}
 	fprintf(stderr, "[bwa_oracle] aligned %lld reads in %.3f s with %d threads (process_seqs only)\n", (long long)n_processed, t_align, opt.n_threads);
 	gzclose(f1.fp); if (f2.fp) gzclose(f2.fp);
+	free(f1.line); free(f2.line);
 	ora_index_destroy(idx);
 	return 0;
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the summaries of a scripts/profile_round.sh run (gpurun_out/<tag>/) into profiles/<round>/ (tracked).
 usage: scripts/collect_profiles.py <tag> <round-dir>"""
-import csv, glob, json, os, re, shutil, sys, collections
+import csv, glob, hashlib, json, os, re, shutil, sys, collections
 
 tag, dst = sys.argv[1], sys.argv[2]
 traffic_only = "--traffic-only" in sys.argv       # on the GPU box: only (re)write profiles/pmc_traffic.json
@@ -34,8 +34,11 @@ key = [k for k in tot if k.startswith("k_smem") and "heavy" not in k]
 if key:
     t = tot[key[0]]; n = calls[key[0]]
     bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
-    out = {"workload": bench["config"]["workload"], "kernel": key[0],
+    sha = hashlib.sha256()
+    for f in ("k_smem.hip", "fmi_dev.h"):
+        sha.update(open(os.path.join("bwa-mem-gpu_amd", "csrc", f), "rb").read())
+    out = {"launch_workload": bench["config"]["launch_workload"], "kernel": key[0], "kernel_src_sha256": sha.hexdigest(),
            "fetch_bytes_per_launch": t["FETCH_SIZE"] / n["FETCH_SIZE"] * 1024, "write_bytes_per_launch": t["WRITE_SIZE"] / n["WRITE_SIZE"] * 1024,
-           "source": f"{dst}/pmc_bench_default.csv (separate rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`)"}
+           "source": f"{dst}/pmc_bench_default.csv (separate rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 0 --reads 2000000 --no-cpu-baseline --no-e2e`; per launch = per batch of 1 M reads)"}
     json.dump(out, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
     print(out)
