@@ -97,6 +97,7 @@ def lib():
     L.bwahip_init_from_files.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.bwahip_rccl_unique_id.argtypes = [vp]
     L.bwahip_init_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.bwahip_ctx_clone.argtypes = [vp, C.POINTER(vp)]
     L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
     L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
@@ -205,6 +206,13 @@ class Context:
         idb = C.create_string_buffer(bytes(unique_id), 128)
         _check(lib().bwahip_init_rccl(os.fsencode(prefix) if prefix is not None else None, rank, world, idb, device, C.byref(self._h)), "bwahip_init_rccl")
         return self
+
+    def clone(self):
+        """A further context on the same GPU sharing this one's index in HBM (bwahip_ctx_clone); keep `self` alive longer."""
+        other = Context(None)
+        _check(lib().bwahip_ctx_clone(self._h, C.byref(other._h)), "bwahip_ctx_clone")
+        other._keep = self
+        return other
 
     def close(self):
         if self._h:

@@ -52,6 +52,7 @@ struct Knobs {
 	int gpu_final = 1;          // BWAHIP_GPU_FINAL: 0 = finalisation of single-end batches on host threads (host_final.cpp) instead of the GPU kernels
 	int gpu_pair = 1;           // BWAHIP_GPU_PAIR: 0 = paired-end batches finalised on host threads (mate rescue, pairing, SAM)
 	int verbose = 0;            // BWAHIP_VERBOSE
+	int e2e_log = 0;            // BWAHIP_E2E_LOG: one line of phase timings per bwahip_process_seqs call
 	const char *dump_ext = nullptr;   // BWAHIP_DUMP_EXT (diagnostic)
 	void from_env()
 	{
@@ -59,18 +60,30 @@ struct Knobs {
 		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult);
 		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final); geti("BWAHIP_GPU_PAIR", gpu_pair);
 		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
+		e2e_log = getenv("BWAHIP_E2E_LOG") != nullptr;
 		dump_ext = getenv("BWAHIP_DUMP_EXT");
 		if (intv_cap < 2) intv_cap = 2;
 	}
 };
 
+// offsets of one host batch on its way to HBM (bwahip_process_seqs)
+struct BatchText {
+	std::vector<int64_t> off, qoff, noff, coff;
+	int64_t qtot = 0;
+	bool any_comment = false;
+	size_t sz_codes = 0, sz_qual = 0, sz_names = 0, sz_comm = 0;
+};
+
 struct bwahip_ctx {
+	BatchText batch_text;
 	bool external_index = false;
 	bool index_resident = false;         // d_bwt / d_sa / d_pac were filled before ctx_setup (bwahip_init_rccl)
 	Knobs knobs;
 	std::string rg_id;                   // read-group id appended as RG:Z: to every record (bwa_rg_id, bwa.c:44); empty = none
 	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
+	hipStream_t stream_copy = nullptr;   // uploads that run beside the kernels (bwahip_process_seqs: names / qualities during the hot path)
+	hipEvent_t ev_slice[8] = {};         // bwahip_process_seqs: one per slice of the SAM download
 	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
 	HostIndex host = {};                 // host copy: contig table + packed reference (always owned); FM-index arrays only when loaded from files
@@ -108,6 +121,7 @@ struct bwahip_ctx {
 
 extern "C" int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac);   // streams, tables, DevIndex
 int launch_scan(const int *in, int64_t *out, int n, DevBuf &tmp, hipStream_t st);   // exclusive scan int32 -> int64, n+1 outputs
+int launch_nt4(uint8_t *seq, int64_t n, hipStream_t st);   // runtime.hip: ASCII / codes -> codes 0..4 in place (nst_nt4_table)
 int dev_upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st);
 int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump);      // the hot path over the uploaded batch
 int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const bwahip_pestat_t *pes0, bool timed);   // regions in HBM -> SAM text in HBM (SE, or PE when opt->flag has MEM_F_PE)

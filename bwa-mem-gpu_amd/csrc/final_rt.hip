@@ -231,7 +231,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 		int n_redo = h[2], err = h[4];
 		if (err == 5 && attempt < 6) { want_pool *= 4; continue; }     // text pool exhausted: larger pool, run the stage again (GPU only)
 		if (!err && n_redo > 0) {                                       // tasks beyond the LDS variant: global-slab variant
-			const int grid = std::min(n_redo, 32);
+			const int grid = std::min(n_redo, 256);                   // one 5.7 MB slab per workgroup
 			if ((rc = c->d_bigz.ensure((size_t)grid * cigar_big_slab_bytes()))) return rc;
 			f.big_z = c->d_bigz.as<uint8_t>();
 			if ((rc = launch_cigar_big(f, grid, c->stream))) return rc;
@@ -269,58 +269,137 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	return 0;
 }
 
-static const uint8_t k_nt4[256] = {      // nst_nt4_table, bntseq.c:46
-	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
-	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,5,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
-	4,0,4,1, 4,4,4,2, 4,4,4,4, 4,4,4,4,  4,4,4,4, 3,4,4,4, 4,4,4,4, 4,4,4,4,
-	4,0,4,1, 4,4,4,2, 4,4,4,4, 4,4,4,4,  4,4,4,4, 3,4,4,4, 4,4,4,4, 4,4,4,4,
-	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
-	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
-	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,
+#define NT4_TABLE \
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4, \
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,5,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4, \
+	4,0,4,1, 4,4,4,2, 4,4,4,4, 4,4,4,4,  4,4,4,4, 3,4,4,4, 4,4,4,4, 4,4,4,4, \
+	4,0,4,1, 4,4,4,2, 4,4,4,4, 4,4,4,4,  4,4,4,4, 3,4,4,4, 4,4,4,4, 4,4,4,4, \
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4, \
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4, \
+	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4, \
 	4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4,  4,4,4,4, 4,4,4,4, 4,4,4,4, 4,4,4,4
-};
+static const uint8_t k_nt4[256] = { NT4_TABLE };      // nst_nt4_table, bntseq.c:46
+__constant__ uint8_t d_nt4[256] = { NT4_TABLE };
 
-// Upload one batch of host reads: base codes (converted in place exactly as bwamem.c:1067-1068 does), qualities, names, comments.
-static int upload_batch_text(bwahip_ctx *c, int nt, int n, bwahip_seq_t *seqs)
+// bwamem.c:1067-1068 on the batch in HBM: seq[i] = seq[i] < 4 ? seq[i] : nst_nt4_table[seq[i]] (seq is char: bytes >= 128 compare
+// below 4 and stay as they are, as in the reference), 16 bases per thread
+__global__ __launch_bounds__(256) void k_nt4_conv(uint8_t *seq, int64_t n)
 {
-	std::vector<int64_t> off(n + 1, 0), qoff(n, -1), noff(n + 1, 0), coff(n + 1, 0);
-	int64_t qtot = 0;
-	bool any_comment = false;
-	for (int i = 0; i < n; ++i) {
-		if (seqs[i].l_seq < 0 || !seqs[i].name) return BWAHIP_EINVAL;
-		off[i + 1] = off[i] + seqs[i].l_seq;
-		if (seqs[i].qual) { qoff[i] = qtot; qtot += seqs[i].l_seq; }
-		noff[i + 1] = noff[i] + (int64_t)strlen(seqs[i].name) + 1;
-		const int64_t lc = seqs[i].comment ? (int64_t)strlen(seqs[i].comment) : 0;
-		coff[i + 1] = coff[i] + (lc ? lc + 1 : 0);
-		any_comment |= lc > 0;
+	const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+	if (i >= n) return;
+	if (i + 16 <= n) {
+		uint4 v = *reinterpret_cast<const uint4*>(seq + i);
+		uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			uint32_t o = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b) { const uint32_t c = w[k] >> (8 * b) & 0xff; o |= (uint32_t)(((int8_t)c < 4) ? c : d_nt4[c]) << (8 * b); }
+			w[k] = o;
+		}
+		*reinterpret_cast<uint4*>(seq + i) = make_uint4(w[0], w[1], w[2], w[3]);
+	} else for (int64_t k = i; k < n; ++k) { const uint8_t c = seq[k]; seq[k] = ((int8_t)c < 4) ? c : d_nt4[c]; }
+}
+int launch_nt4(uint8_t *seq, int64_t n, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_nt4_conv, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, st, seq, n);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+// One batch of host reads on its way to HBM.  The base codes go first (converted in place exactly as bwamem.c:1067-1068 does)
+// and the hot path starts on them at once; qualities, names and comments -- needed only when the SAM text is written -- are
+// gathered and uploaded by a helper thread on the copy stream while the hot path runs.
+static int stage_codes(bwahip_ctx *c, int nt, int n, bwahip_seq_t *seqs, BatchText &t)
+{
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
+	t.off.resize(n + 1); t.qoff.resize(n); t.noff.resize(n + 1); t.coff.resize(n + 1);
+	t.off[0] = t.noff[0] = t.coff[0] = 0;
+	// offsets of bases / qualities / names / comments: per-chunk totals in parallel (two strlen per read), a serial scan over the
+	// chunks, then the running sums inside every chunk in parallel
+	const int C = n >= 4096 && nt > 1 ? nt : 1;
+	struct Tot { int64_t seq = 0, qual = 0, name = 0, comm = 0; int bad = 0, any_comm = 0; char pad[24]; };
+	std::vector<Tot> tot(C + 1);
+	auto chunk = [&](int c) { return (int64_t)n * c / C; };
+	auto for_chunks = [&](auto f) {
+		if (C == 1) { f(0); return; }
+		std::vector<std::thread> th;
+		for (int c = 0; c < C; ++c) th.emplace_back(f, c);
+		for (auto &x : th) x.join();
+	};
+	for_chunks([&](int c) {
+		Tot x;
+		for (int64_t i = chunk(c); i < chunk(c + 1); ++i) {
+			if (seqs[i].l_seq < 0 || !seqs[i].name) { x.bad = 1; continue; }
+			const int64_t ln = (int64_t)strlen(seqs[i].name) + 1, lc = seqs[i].comment ? (int64_t)strlen(seqs[i].comment) : 0;
+			t.noff[i + 1] = ln; t.coff[i + 1] = lc ? lc + 1 : 0;
+			x.seq += seqs[i].l_seq; x.qual += seqs[i].qual ? seqs[i].l_seq : 0; x.name += ln; x.comm += lc ? lc + 1 : 0; x.any_comm |= lc > 0;
+		}
+		tot[c + 1] = x;
+	});
+	for (int c = 1; c <= C; ++c) {
+		if (tot[c].bad) return BWAHIP_EINVAL;
+		t.any_comment |= tot[c].any_comm != 0;
+		tot[c].seq += tot[c - 1].seq; tot[c].qual += tot[c - 1].qual; tot[c].name += tot[c - 1].name; tot[c].comm += tot[c - 1].comm;
 	}
-	// one pinned staging buffer (kept by the context) holds codes | qualities | names | comments: the copies to HBM then run at
-	// PCIe speed instead of through pageable memory
-	const size_t sz_codes = ((size_t)off[n] + 64) & ~(size_t)63, sz_qual = ((size_t)qtot + 127) & ~(size_t)63, sz_names = ((size_t)noff[n] + 127) & ~(size_t)63,
-	             sz_comm = any_comment ? ((size_t)coff[n] + 127) & ~(size_t)63 : 0;
-	int rc = c->h_stage.ensure(sz_codes + sz_qual + sz_names + sz_comm);
-	if (rc) return rc;
-	uint8_t *codes = (uint8_t*)c->h_stage.p, *qual = codes + sz_codes, *names = qual + sz_qual, *comments = names + sz_names;
-	memset(qual + (size_t)qtot, 0, sz_qual - (size_t)qtot); memset(names + (size_t)noff[n], 0, sz_names - (size_t)noff[n]);
-	if (any_comment) memset(comments + (size_t)coff[n], 0, sz_comm - (size_t)coff[n]);
-	par_for_chunks(n, nt, [&](int64_t b, int64_t e) {
-		for (int64_t i = b; i < e; ++i) {
-			char *s = seqs[i].seq;
-			for (int k = 0; k < seqs[i].l_seq; ++k) { s[k] = s[k] < 4 ? s[k] : (char)k_nt4[(uint8_t)s[k]]; codes[off[i] + k] = (uint8_t)s[k]; }
-			if (qoff[i] >= 0) memcpy(&qual[qoff[i]], seqs[i].qual, seqs[i].l_seq);
-			memcpy(&names[noff[i]], seqs[i].name, noff[i + 1] - noff[i]);
-			if (any_comment && coff[i + 1] > coff[i]) memcpy(&comments[coff[i]], seqs[i].comment, coff[i + 1] - coff[i]);
+	t.qtot = tot[C].qual;
+	for_chunks([&](int c) {
+		int64_t so = tot[c].seq, qo = tot[c].qual, no = tot[c].name, co = tot[c].comm;
+		for (int64_t i = chunk(c); i < chunk(c + 1); ++i) {
+			so += seqs[i].l_seq; t.off[i + 1] = so;
+			if (seqs[i].qual) { t.qoff[i] = qo; qo += seqs[i].l_seq; } else t.qoff[i] = -1;
+			no += t.noff[i + 1]; t.noff[i + 1] = no;
+			co += t.coff[i + 1]; t.coff[i + 1] = co;
 		}
 	});
-	rc = bwahip_batch_upload(c, n, codes, off.data());
+	const double t1 = now();
+	// one pinned staging buffer (kept by the context) holds codes | qualities | names | comments: the copies to HBM then run at
+	// PCIe speed instead of through pageable memory
+	t.sz_codes = ((size_t)t.off[n] + 64) & ~(size_t)63; t.sz_qual = ((size_t)t.qtot + 127) & ~(size_t)63; t.sz_names = ((size_t)t.noff[n] + 127) & ~(size_t)63;
+	t.sz_comm = t.any_comment ? ((size_t)t.coff[n] + 127) & ~(size_t)63 : 0;
+	int rc = c->h_stage.ensure(t.sz_codes + t.sz_qual + t.sz_names + t.sz_comm);
 	if (rc) return rc;
-	if ((rc = dev_upload(c->d_qual, qual, sz_qual, c->stream)) || (rc = dev_upload(c->d_qual_off, qoff.data(), (size_t)n * 8, c->stream)) ||
-	    (rc = dev_upload(c->d_names, names, sz_names, c->stream)) || (rc = dev_upload(c->d_name_off, noff.data(), (size_t)(n + 1) * 8, c->stream)) ||
-	    (rc = dev_upload(c->d_comment_off, coff.data(), (size_t)(n + 1) * 8, c->stream))) return rc;
-	if (any_comment) { if ((rc = dev_upload(c->d_comments, comments, sz_comm, c->stream))) return rc; }
+	// device buffers of the text are sized here, on the calling thread, so that the helper only copies
+	if ((rc = c->d_qual.ensure(t.sz_qual)) || (rc = c->d_qual_off.ensure((size_t)n * 8 + 16)) || (rc = c->d_names.ensure(t.sz_names)) ||
+	    (rc = c->d_name_off.ensure((size_t)(n + 1) * 8)) || (rc = c->d_comment_off.ensure((size_t)(n + 1) * 8))) return rc;
+	if (t.any_comment) { if ((rc = c->d_comments.ensure(t.sz_comm))) return rc; }
 	else c->d_comments.release();
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	// the bases travel as the caller wrote them (ASCII or codes) and are turned into codes in HBM (k_nt4: the same table look-up as
+	// bwamem.c:1067-1068); the caller's own arrays are converted in place by the helper thread while the hot path runs
+	const double t2 = now();
+	uint8_t *codes = (uint8_t*)c->h_stage.p;
+	par_for_chunks(n, nt, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) memcpy(codes + t.off[i], seqs[i].seq, (size_t)seqs[i].l_seq); });
+	const double t3 = now();
+	if ((rc = bwahip_batch_upload(c, n, codes, t.off.data()))) return rc;
+	if (c->knobs.e2e_log) fprintf(stderr, "[bwahip] stage_codes: offsets %.1f ms, buffers %.1f ms, gather %.1f ms, upload %.1f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now() - t3) * 1e3);
+	return launch_nt4(c->d_seq.as<uint8_t>(), c->total_bases, c->stream);
+}
+
+// helper thread: the text of the batch into the pinned buffer and on to HBM (copy stream); returns when the copies are done
+static int stage_text(bwahip_ctx *c, int nt, int n, bwahip_seq_t *seqs, const BatchText &t)
+{
+	HIP_TRY(hipSetDevice(c->device));
+	uint8_t *qual = (uint8_t*)c->h_stage.p + t.sz_codes, *names = qual + t.sz_qual, *comments = names + t.sz_names;
+	memset(qual + (size_t)t.qtot, 0, t.sz_qual - (size_t)t.qtot); memset(names + (size_t)t.noff[n], 0, t.sz_names - (size_t)t.noff[n]);
+	if (t.any_comment) memset(comments + (size_t)t.coff[n], 0, t.sz_comm - (size_t)t.coff[n]);
+	par_for_chunks(n, nt, [&](int64_t b, int64_t e) {
+		for (int64_t i = b; i < e; ++i) {
+			char *s = seqs[i].seq;                                  // bwamem.c:1067-1068, in place (the reference's contract)
+			for (int k = 0; k < seqs[i].l_seq; ++k) s[k] = s[k] < 4 ? s[k] : (char)k_nt4[(uint8_t)s[k]];
+			if (t.qoff[i] >= 0) memcpy(&qual[t.qoff[i]], seqs[i].qual, seqs[i].l_seq);
+			memcpy(&names[t.noff[i]], seqs[i].name, t.noff[i + 1] - t.noff[i]);
+			if (t.any_comment && t.coff[i + 1] > t.coff[i]) memcpy(&comments[t.coff[i]], seqs[i].comment, t.coff[i + 1] - t.coff[i]);
+		}
+	});
+	hipStream_t st = c->stream_copy;
+	HIP_TRY(hipMemcpyAsync(c->d_qual.p, qual, t.sz_qual, hipMemcpyHostToDevice, st));
+	if (n) HIP_TRY(hipMemcpyAsync(c->d_qual_off.p, t.qoff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(c->d_names.p, names, t.sz_names, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(c->d_name_off.p, t.noff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(c->d_comment_off.p, t.coff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	if (t.any_comment) HIP_TRY(hipMemcpyAsync(c->d_comments.p, comments, t.sz_comm, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
 	return 0;
 }
 
@@ -336,33 +415,62 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	const bool verbose = ctx->knobs.verbose != 0;
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = now();
-	int rc = upload_batch_text(ctx, opt->n_threads, n, seqs);
+	const int nt = opt->n_threads > 1 ? opt->n_threads : 1;
+	BatchText &bt = ctx->batch_text;                             // kept by the context: no fresh page faults per batch
+	bt.qtot = 0; bt.any_comment = false;
+	int rc = stage_codes(ctx, nt, n, seqs, bt);
 	if (rc) return rc;
 	const double t1 = now();
-	if ((rc = run_pipeline(ctx, opt, false, false))) return rc;
+	// the text travels while the hot path runs (half of the host threads: the other half of the machine belongs to the caller's reader)
+	int rc_text = 0;
+	std::thread text_thread([&] { rc_text = stage_text(ctx, nt > 2 ? nt / 2 : 1, n, seqs, bt); });
+	rc = run_pipeline(ctx, opt, false, false);
+	text_thread.join();
+	if (rc || (rc = rc_text)) return rc;
 	const double t2 = now();
 	if ((rc = run_final(ctx, opt, n_processed, pes0, false))) return rc;
-	// SAM text back in one piece (pinned staging buffer, on the context's stream: it is a non-blocking stream, a plain hipMemcpy
-	// would not wait for the SAM kernel), then one malloc()ed string per read as the reference's contract wants (bwamem.c:1054)
+	// SAM text back through the pinned buffer, on the context's stream (a non-blocking stream: a plain hipMemcpy would not wait
+	// for the SAM kernel), in slices of reads: while slice k+1 travels, the host threads cut slice k into one malloc()ed string
+	// per read, which is what the reference's contract wants (bwamem.c:1054)
 	std::vector<int64_t> soff(n + 1);
 	if ((rc = ctx->h_sam.ensure((size_t)ctx->total_sam + 1))) return rc;
 	char *text = (char*)ctx->h_sam.p;
 	HIP_TRY(hipMemcpyAsync(soff.data(), ctx->d_sam_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-	if (ctx->total_sam) HIP_TRY(hipMemcpyAsync(text, ctx->d_sam.p, (size_t)ctx->total_sam, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	constexpr int SLICES = 8;
+	int n_sl = 0;
+	int64_t sl_beg[SLICES + 1];
+	for (int k = 0; k <= SLICES; ++k) sl_beg[k] = (int64_t)n * k / SLICES;
+	for (int k = 0; k < SLICES; ++k) {
+		const int64_t b = soff[sl_beg[k]], e = soff[sl_beg[k + 1]];
+		if (e > b) HIP_TRY(hipMemcpyAsync(text + b, (const char*)ctx->d_sam.p + b, (size_t)(e - b), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipEventRecord(ctx->ev_slice[k], ctx->stream));
+		n_sl = k + 1;
+	}
 	const double t3 = now();
-	std::atomic<int> oom(0);
-	par_for_chunks(n, opt->n_threads, [&](int64_t b, int64_t e) {
-		for (int64_t i = b; i < e; ++i) {
-			const size_t len = (size_t)(soff[i + 1] - soff[i]);
-			char *p = (char*)malloc(len + 1);
-			if (!p) { oom = 1; seqs[i].sam = nullptr; continue; }
-			memcpy(p, text + soff[i], len); p[len] = 0;
-			seqs[i].sam = p;
+	std::atomic<int> oom(0), hip_bad(0);
+	auto cut = [&](int tid, int nthr) {
+		(void)hipSetDevice(ctx->device);
+		for (int k = 0; k < n_sl; ++k) {
+			if (hipEventSynchronize(ctx->ev_slice[k]) != hipSuccess) { hip_bad = 1; return; }
+			const int64_t cnt = sl_beg[k + 1] - sl_beg[k], per = (cnt + nthr - 1) / nthr;
+			const int64_t b = sl_beg[k] + tid * per, e = b + per < sl_beg[k + 1] ? b + per : sl_beg[k + 1];
+			for (int64_t i = b; i < e; ++i) {
+				const size_t len = (size_t)(soff[i + 1] - soff[i]);
+				char *p = (char*)malloc(len + 1);
+				if (!p) { oom = 1; seqs[i].sam = nullptr; continue; }
+				memcpy(p, text + soff[i], len); p[len] = 0;
+				seqs[i].sam = p;
+			}
 		}
-	});
-	if (verbose) fprintf(stderr, "[bwahip] process_seqs %d reads: gather+upload %.1f ms, hot path %.1f ms, finalisation+SAM on GPU+download %.1f ms (%lld bytes), per-read strings %.1f ms\n",
-	                     n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)ctx->total_sam, (now() - t3) * 1e3);
+	};
+	if (nt == 1) cut(0, 1);
+	else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(cut, t, nt); for (auto &x : th) x.join(); }
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if (verbose || ctx->knobs.e2e_log)
+		fprintf(stderr, "[bwahip] process_seqs %d reads: codes gather+upload %.1f ms, hot path (text upload beside it) %.1f ms, finalisation+SAM on GPU %.1f ms (%lld bytes), download + per-read strings %.1f ms\n",
+		        n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)ctx->total_sam, (now() - t3) * 1e3);
+	if (hip_bad) return BWAHIP_ENODEV;
 	return oom ? BWAHIP_ENOMEM : 0;
 }
 

@@ -330,6 +330,60 @@ __device__ int wave_global_trace(const Sw &sw, const uint8_t *q, int qs, int qle
 }
 
 
+// ksw_global2 for a band of at most 64 diagonals (2w + 1 <= 64) -- what mem_reg2aln nearly always asks for (w = 3 .. 30 for a
+// 150 bp read with a few mismatches or a short gap).  One lane per DIAGONAL k = j - i + w of the band, cells taken in
+// anti-diagonal order: at step s lane k computes cell i = (s - k) / 2, j = i - w + k (every lane works every other step).
+// Its three inputs are then exactly one step old: H(i-1,j-1) is the lane's own previous cell, E comes from lane k + 1's previous
+// cell (i-1,j) and F from lane k - 1's previous cell (i,j-1) -- two DPP moves per step, no scan for F and no lanes idling
+// outside the band as in the row-wise form.  Every cell evaluates ksw.c:548-572 literally, so H, E, F and the backtrack bytes are
+// those of the reference whatever the order.  Needs w >= |tlen - qlen| (bwa.c:293-300 guarantees w >= |..| + 3): then no row is
+// empty and the last row reaches column qlen - 1.  Returns the score (ksw.c:583).
+__device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col)
+{
+	const int k = lane();
+	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
+	// the cell before the first one of this diagonal lies on the border: row -1 (ksw.c:523-526) or column -1 (ksw.c:541)
+	int Hd = k >= w ? (k == w ? 0 : -(sw.o_ins + e_ins * (k - w))) : -(sw.o_del + e_del * (w - k));
+	int Eout = NEG, Fout = NEG;
+	const int k_last = qlen - tlen + w;                          // diagonal of the corner cell (tlen-1, qlen-1)
+	const int steps = 2 * (tlen - 1) + k_last;                   // its step; nothing after it matters
+	int i = k >= w ? 0 : w - k, j = k >= w ? k - w : 0;          // first cell of this diagonal; every next one is (i+1, j+1)
+	// the substitution score of a cell does not depend on the DP: it is looked up one cell ahead, and the two bases it needs two
+	// cells ahead, so that no step waits on a chain of LDS round trips (indices clamped: values past the end are never used)
+	auto ldt = [&](int ii) { return (int)t[(ii < tlen ? ii : tlen - 1) * ts]; };
+	auto ldq = [&](int jj) { return (int)q[(jj < qlen ? jj : qlen - 1) * qs]; };
+	int sc_next = sw.mat[ldt(i) * 5 + ldq(j)];
+	int tn = ldt(i + 1), qn = ldq(j + 1);
+	const bool mine = k <= 2 * w;
+	for (int s = 0; s <= steps; ++s) {
+		const int Ein = __builtin_amdgcn_update_dpp(NEG, Eout, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane k <- lane k + 1
+		const int Fin = __builtin_amdgcn_update_dpp(NEG, Fout, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane k <- lane k - 1
+		if (mine && s - k == 2 * i && i < tlen && j < qlen) {
+			const int m = Hd + sc_next;
+			sc_next = sw.mat[tn * 5 + qn];
+			tn = ldt(i + 2); qn = ldq(j + 2);
+			int e = (i >= 1 && k < 2 * w) ? Ein : NEG;             // ksw.c:582 / 527: no cell above inside the band
+			int f = (j >= 1 && k >= 1) ? Fin : NEG;                // ksw.c:538: f starts at MINUS_INF in every row
+			int d = m >= e ? 0 : 1;
+			int h = m >= e ? m : e;
+			d = h >= f ? d : 2;
+			h = h >= f ? h : f;
+			const int tD = m - oe_del;
+			e -= e_del;
+			d |= e > tD ? 1 << 2 : 0;
+			Eout = e > tD ? e : tD;
+			const int tI = m - oe_ins;
+			f -= e_ins;
+			d |= f > tI ? 2 << 4 : 0;
+			Fout = f > tI ? f : tI;
+			z[(size_t)i * n_col + (i > w ? k : j)] = (uint8_t)d;  // zi[j - beg], beg = max(0, i - w)
+			Hd = h;
+			++i; ++j;
+		}
+	}
+	return __builtin_amdgcn_readlane(Hd, k_last);
+}
+
 // decimal digits of a non-negative integer into dst; returns the count
 __device__ __forceinline__ int put_uint(uint8_t *dst, unsigned v)
 {
@@ -339,7 +393,7 @@ __device__ __forceinline__ int put_uint(uint8_t *dst, unsigned v)
 	return n;
 }
 
-struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; };
+struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; int max_c, max_md; };   // max_c / max_md: capacity of cig / md
 
 // One task: region `ar` of read r -> DevAln (+ CIGAR words and MD text appended to the pool).  BIG: window / matrix in the
 // workgroup's global slab.  Returns false when the task does not fit this variant (caller lists it for k_cigar_big).
@@ -402,7 +456,8 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			__syncthreads();
 			// the fewest columns per lane that hold the query; CPLMAX (from the longest read of the batch) bounds what is
 			// compiled in, and with it the registers of the kernel
-			if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			if (2 * w + 1 <= 64) score = wave_band_trace(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 2 || lq < 128) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 3 || lq < 192) score = wave_global_trace<(CPLMAX < 3 ? CPLMAX : 3)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 4 || lq < 256) score = wave_global_trace<(CPLMAX < 4 ? CPLMAX : 4)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
@@ -415,7 +470,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 				uint32_t cur = 0; bool have = false, ovf = false;
 				auto push = [&](int op, int len) {
 					if (have && (int)(cur & 0xf) == op) cur += (uint32_t)len << 4;
-					else { if (have) { if (nc < CG_MAXC) m.cig[nc] = cur; else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
+					else { if (have) { if (nc < m.max_c) m.cig[nc] = cur; else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
 				};
 				while (i >= 0 && k >= 0) {
 					which = m.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
@@ -425,7 +480,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 				}
 				if (i >= 0) push(2, i + 1);
 				if (k >= 0) push(1, k + 1);
-				if (have) { if (nc < CG_MAXC) m.cig[nc] = cur; else ovf = true; ++nc; }
+				if (have) { if (nc < m.max_c) m.cig[nc] = cur; else ovf = true; ++nc; }
 				if (ovf) nc = -1;
 				else for (int x = 0; x < nc >> 1; ++x) { const uint32_t tmp = m.cig[x]; m.cig[x] = m.cig[nc - 1 - x]; m.cig[nc - 1 - x] = tmp; }
 			}
@@ -445,7 +500,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 	{
 		int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
 		bool md_ovf = false;
-		auto emit_num = [&](int v) { if (md_len + 11 < CG_MAXMD) { if (l == 0) md_len += put_uint(m.md + md_len, (unsigned)v); } else md_ovf = true; };
+		auto emit_num = [&](int v) { if (md_len + 11 < m.max_md) { if (l == 0) md_len += put_uint(m.md + md_len, (unsigned)v); } else md_ovf = true; };
 		// md_len is advanced by lane 0 only; it is broadcast after every variable-length emission
 		const char *int2base = rev ? "TGCAN" : "ACGTN";
 		for (int k = 0; k < n_cigar; ++k) {
@@ -463,7 +518,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 						u += p - prev;
 						emit_num(u);
 						md_len = __shfl(md_len, 0);
-						if (md_len + 1 < CG_MAXMD) { if (l == 0) m.md[md_len] = (uint8_t)int2base[tp[(y + base + p) * ts]]; ++md_len; } else md_ovf = true;
+						if (md_len + 1 < m.max_md) { if (l == 0) m.md[md_len] = (uint8_t)int2base[tp[(y + base + p) * ts]]; ++md_len; } else md_ovf = true;
 						++n_mm; u = 0; prev = p + 1;
 					}
 					const int chunk = len - base < 64 ? len - base : 64;
@@ -474,7 +529,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 				if (k > 0 && k < n_cigar - 1) {
 					emit_num(u);
 					md_len = __shfl(md_len, 0);
-					if (md_len + 1 + len < CG_MAXMD) {
+					if (md_len + 1 + len < m.max_md) {
 						if (l == 0) m.md[md_len] = '^';
 						for (int i = l; i < len; i += 64) m.md[md_len + 1 + i] = (uint8_t)int2base[tp[(y + i) * ts]];
 						md_len += 1 + len;
@@ -534,11 +589,16 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 template <bool FAST, int CPLMAX>
 __global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
 {
+	// LDS per task, sized by the read-length class of the batch (CPLMAX <= 3: reads below 192 bases; FAST tasks span exactly
+	// their query, at most BWAHIP_MAX_READ_LEN, and have one CIGAR operation): what does not fit goes to k_cigar_big.  The
+	// kernel waits on chains of dependent LDS / global loads, so the number of tasks in flight per CU is what matters
+	constexpr bool SMALL = FAST || CPLMAX <= 3;
+	constexpr int TCAP = SMALL ? 768 : CG_MAXT, ZL = FAST ? 16 : SMALL ? 8192 : CG_ZLDS, MC = FAST ? 8 : SMALL ? 160 : CG_MAXC, MMD = SMALL ? 512 : CG_MAXMD;
 	__shared__ uint8_t s_q[CG_MAXQ + 8];
-	__shared__ uint8_t s_t[CG_MAXT + 8];
-	__shared__ uint8_t s_z[FAST ? 16 : CG_ZLDS];
-	__shared__ uint32_t s_cig[FAST ? 8 : CG_MAXC];
-	__shared__ uint8_t s_md[CG_MAXMD];
+	__shared__ uint8_t s_t[TCAP + 8];
+	__shared__ uint8_t s_z[ZL];
+	__shared__ uint32_t s_cig[MC];
+	__shared__ uint8_t s_md[MMD];
 	__shared__ int8_t s_mat[32];
 	const int l = lane();
 	if ((int)blockIdx.x >= n_list) return;
@@ -551,8 +611,8 @@ __global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
 	if (l < 25) s_mat[l] = a.opt.mat[l];
 	__syncthreads();
 	const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
-	const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat };
-	if (!reg2aln<false, FAST, CPLMAX>(a, ar, r, t, m, CG_MAXT, FAST ? 0 : CG_ZLDS, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
+	const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat, MC, MMD };
+	if (!reg2aln<false, FAST, CPLMAX>(a, ar, r, t, m, TCAP, FAST ? 0 : ZL, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
 }
 
 // tasks whose reference span, backtrack matrix, CIGAR or MD did not fit LDS: the same code on this workgroup's global slab
@@ -576,7 +636,7 @@ __global__ __launch_bounds__(64) void k_cigar_big(FinLaunch a)
 		if (l < 25) s_mat[l] = a.opt.mat[l];
 		__syncthreads();
 		const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
-		const CigarLds m = { s_q, slab + CG_BIG_Z, slab, s_cig, s_md, s_mat };
+		const CigarLds m = { s_q, slab + CG_BIG_Z, slab, s_cig, s_md, s_mat, CG_MAXC, CG_MAXMD };
 		if (!reg2aln<true>(a, ar, r, t, m, CG_BIG_T, CG_BIG_Z, a.alns + t) && l == 0) { atomicExch(a.err, 6); atomicExch(a.err + 1, r); }
 	}
 }

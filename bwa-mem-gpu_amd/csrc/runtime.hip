@@ -156,6 +156,8 @@ int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, c
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+	for (auto &e : c->ev_slice) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -232,6 +234,20 @@ int bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, con
 	return 0;
 }
 
+// A further context on the same GPU that shares src's index arrays in HBM (nothing is copied on the device): its own streams,
+// batch buffers and host thread.  Two contexts taking batches in turn keep the GPU busy through each other's latency-bound
+// kernels and serial tails (double buffering).  src must outlive the clone.
+int bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out)
+{
+	if (!src || !out || !src->d_bwt.p || !src->d_sa.p || !src->d_pac.p) return BWAHIP_EINVAL;
+	bwahip_bwt_t b = src->host.bwt;
+	b.bwt = (uint32_t*)src->d_bwt.p; b.sa = (uint64_t*)src->d_sa.p;
+	int rc = bwahip_init_device(&b, &src->host.bns, (const uint8_t*)src->d_pac.p, src->device, out);
+	if (rc) return rc;
+	(*out)->knobs = src->knobs; (*out)->intv_cap = src->knobs.intv_cap; (*out)->rg_id = src->rg_id;
+	return 0;
+}
+
 int bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out)
 {
 	if (!prefix || !out) return BWAHIP_EINVAL;
@@ -270,6 +286,8 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream3) (void)hipStreamDestroy(c->stream3);
+	if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
+	for (auto &e : c->ev_slice) if (e) (void)hipEventDestroy(e);
 	if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);

@@ -174,6 +174,10 @@ int  bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, co
  * caller's own means (MPI, a file, torch.distributed ...).  prefix is read on rank 0 only.  Collective: every rank calls it. */
 int  bwahip_rccl_unique_id(void *id128);
 int  bwahip_init_rccl(const char *prefix, int rank, int world, const void *id128, int device, bwahip_ctx **out);
+/* A further context on the same GPU sharing src's index arrays in HBM (no device copy; src must outlive it).  Contexts are
+ * independent otherwise (own streams and batch buffers): two of them, each driven by its own host thread and taking batches in
+ * turn, overlap one batch's latency-bound kernels with the other's throughput-bound ones. */
+int  bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out);
 /* Convenience: read a stock `bwa index` file set <prefix>.{bwt,sa,pac,ann,amb[,alt]} (bwa.c:402 bwa_idx_load) and init. */
 int  bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out);
 void bwahip_destroy(bwahip_ctx *ctx);

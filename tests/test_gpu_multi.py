@@ -27,6 +27,42 @@ def test_rccl_broadcast_init_one_rank(small_index, tmp_path):
         assert b"".join(c.process_seqs(names, seqs, quals, opt)) == want
 
 
+def test_two_contexts_sharing_the_index_run_batches_concurrently(small_index, tmp_path):
+    """bwahip_ctx_clone: a second context on the same GPU (index arrays shared in HBM), both driven at once from two host threads
+    (double buffering).  Every batch's SAM must equal the CPU path's whichever context took it, SE and PE."""
+    import threading
+    fq1, fq2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    bw.make_reads(small_index["fa"], fq1, fq2, 3000, 150, 10000, 2000, 500, 151, 20000)
+    n1, s1, q1 = bw.read_fastq(fq1)
+    n2, s2, q2 = bw.read_fastq(fq2)
+    names = [x for p in zip(n1, n2) for x in p]; seqs = [x for p in zip(s1, s2) for x in p]; quals = [x for p in zip(q1, q2) for x in p]
+    batch = 1000 * 150                                           # -K in bases: 6 batches of 1000 reads
+    want_pe = subprocess.run([common.ORACLE, "mem", "-t", "4", "-K", str(batch), small_index["prefix"], fq1, fq2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    want_se = subprocess.run([common.ORACLE, "mem", "-t", "4", "-K", str(batch), small_index["prefix"], fq1], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    with bw.Context(small_index["prefix"]) as c0:
+        c1 = c0.clone()
+        try:
+            for pe, nm, sq, ql, want in ((True, names, seqs, quals, want_pe), (False, n1, s1, q1, want_se)):
+                opt = bw.default_opt()
+                opt.n_threads = 2
+                if pe:
+                    opt.flag |= 0x2
+                out = {}
+
+                def work(t, cx):
+                    for k, b0 in enumerate(range(0, len(sq), 1000)):
+                        if k % 2 == t:
+                            out[b0] = b"".join(cx.process_seqs(nm[b0:b0 + 1000], sq[b0:b0 + 1000], ql[b0:b0 + 1000], opt, n_processed=b0))
+                th = [threading.Thread(target=work, args=(t, cx)) for t, cx in enumerate((c0, c1))]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                assert b"".join(out[k] for k in sorted(out)) == want
+        finally:
+            c1.close()
+
+
 WORKER = textwrap.dedent('''
     import os, sys
     root, prefix, fq1, fq2, batch, out = sys.argv[1:7]
