@@ -98,6 +98,7 @@ def lib():
     L.bwahip_rccl_unique_id.argtypes = [vp]
     L.bwahip_init_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.bwahip_ctx_clone.argtypes = [vp, C.POINTER(vp)]
+    L.bwahip_ctx_set_rg_id.argtypes = [vp, C.c_char_p]
     L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
     L.bwahip_run_stages.argtypes = [vp, C.POINTER(Opt), C.c_int, vp, vp, C.c_int, C.POINTER(i64p), i64p]
@@ -243,6 +244,10 @@ class Context:
         """Set hand-off thresholds of the heavy-read kernels (bwahip_ctx_tune): intv_cap, smem_lanes, heavy_mult, ..."""
         for k, v in kw.items():
             _check(lib().bwahip_ctx_tune(self._h, k.encode(), int(v)), f"bwahip_ctx_tune({k})")
+
+    def set_rg_id(self, rg_id):
+        """Read-group id printed as RG:Z: on every record (bwa mem -R '@RG\\tID:<id>...', bwa_set_rg bwa.c:562); None / '' = none."""
+        _check(lib().bwahip_ctx_set_rg_id(self._h, rg_id.encode() if rg_id else None), "bwahip_ctx_set_rg_id")
 
     def process_seqs(self, names, seqs, quals=None, opt=None, n_processed=0, pes0=None, comments=None):
         """mem_process_seqs: list of names / ASCII reads (/ quals) -> list of SAM text (bytes) per read."""

@@ -152,8 +152,9 @@ typedef struct { uint64_t x[3], info; } bwahip_intv_t;              /* bwtintv_t
 #define BWAHIP_ECAPACITY  -5   /* a read exceeds the compiled limits (length > BWAHIP_MAX_READ_LEN) */
 #define BWAHIP_EINTERNAL  -6   /* a kernel reported an inconsistency (never expected) */
 
-/* Longest read the kernels accept.  Below ~730 bp mem_flt_chained_seeds (bwamem.c:605) returns at its first
- * test (5.5*ln(l) > 0.05*l), so the seed SW filter it would run is provably dormant for every accepted read. */
+/* Longest read the kernels accept (LDS sizing of the per-read kernels).  mem_flt_chained_seeds (bwamem.c:605) runs on the GPU
+ * (k_seed_sw): with the default -W 0 it is active only from ~730 bp, but a caller's -W (opt->min_chain_weight) switches it on
+ * for every read of at least 22*W bases. */
 #define BWAHIP_MAX_READ_LEN 700
 
 typedef struct bwahip_ctx bwahip_ctx;

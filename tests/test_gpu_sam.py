@@ -191,3 +191,41 @@ def test_plain_c_caller_reproduces_golden_sam(built, tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
     assert r.stdout == exp, _first_diff(r.stdout, exp)
     assert b"\tRG:Z:grp1" in r.stdout
+
+
+def test_comments_and_read_group(ctx, small_index, tmp_path):
+    """-C (FASTQ comment appended to every record, bwamem.c:955) and -R (RG:Z: tag, bwamem.c:947) through the GPU SAM kernels,
+    SE and PE, vs the CPU path given the same flags."""
+    fq1, fq2 = str(tmp_path / "c_1.fq"), str(tmp_path / "c_2.fq")
+    bw.make_reads(small_index["fa"], fq1, fq2, 1200, 150, 10000, 2000, 500, 171, 20000)
+    comments = []
+    for path in (fq1, fq2):                                     # two reads in three carry a comment
+        lines = open(path).read().split("\n")
+        for i in range(0, len(lines) - 3, 4):
+            k = i // 4
+            c = f"BC:Z:{'ACGT'[k % 4] * 6}\tXZ:i:{k}" if k % 3 else None
+            if path == fq1:
+                comments.append(c)
+            if c:
+                lines[i] += " " + c
+        open(path, "w").write("\n".join(lines))
+    n1, s1, q1 = bw.read_fastq(fq1)
+    n2, s2, q2 = bw.read_fastq(fq2)
+    rg = ["-R", "@RG\\tID:grp7\\tSM:sample"]
+    body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
+    cm = [c.encode() if c else None for c in comments]
+    ctx.set_rg_id("grp7")
+    try:
+        opt = bw.default_opt()
+        opt.n_threads = 4
+        want = subprocess.run([common.ORACLE, "mem", "-t", "4", "-C", *rg, small_index["prefix"], fq1], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        got = b"".join(ctx.process_seqs(n1, s1, q1, opt, comments=cm))
+        assert b"RG:Z:grp7" in got and b"BC:Z:CCCCCC" in got
+        assert got == body(want)
+        opt.flag |= 0x2
+        want = subprocess.run([common.ORACLE, "mem", "-t", "4", "-C", *rg, small_index["prefix"], fq1, fq2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        names = [x for p in zip(n1, n2) for x in p]; seqs = [x for p in zip(s1, s2) for x in p]; quals = [x for p in zip(q1, q2) for x in p]
+        got = b"".join(ctx.process_seqs(names, seqs, quals, opt, comments=[c for c in cm for _ in (0, 1)]))
+        assert got == body(want)
+    finally:
+        ctx.set_rg_id(None)

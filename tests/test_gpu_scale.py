@@ -64,3 +64,12 @@ def test_bench_workload_sam_identical_to_reference(bench_genome, tmp_path):
         got = b"".join(ctx.process_seqs(names, seqs, quals, opt))
         body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
         assert body(got) == body(want), "SE SAM differs from the CPU path on the bench workload"
+        # PE (configs[2] shape: 2x150, insert N(500,50^2), FR): insert-size statistics, mate rescue, pairing, paired SAM on the GPU
+        reads = tp.make_reads(bench_genome["genome"], bench_genome["lens"], n, 150, sub_ppm=10000, seed=133, paired=True)
+        fqs = tp.write_fastq_fixed(str(tmp_path / "pe"), reads, True)
+        names_pe = tp.fixed_names(n, True)
+        opt.flag |= 0x2
+        want = subprocess.run([exe, "mem", "-t", "8", bench_genome["prefix"], *fqs], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        secs, got = tp.process_seqs_bulk(bw, ctx, opt, names_pe, reads)
+        assert body(got) == body(want), "PE SAM differs from the CPU path on the bench workload"
+        assert ctx.last_pe_stats()[0][1]["failed"] == 0
