@@ -39,6 +39,6 @@ if key:
         sha.update(open(os.path.join("bwa-mem-gpu_amd", "csrc", f), "rb").read())
     out = {"launch_workload": bench["config"]["launch_workload"], "kernel": key[0], "kernel_src_sha256": sha.hexdigest(),
            "fetch_bytes_per_launch": t["FETCH_SIZE"] / n["FETCH_SIZE"] * 1024, "write_bytes_per_launch": t["WRITE_SIZE"] / n["WRITE_SIZE"] * 1024,
-           "source": f"{dst}/pmc_bench_default.csv (separate rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 0 --reads 2000000 --no-cpu-baseline --no-e2e`; per launch = per batch of 1 M reads)"}
+           "source": f"{dst}/pmc_bench_default.csv (separate rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 0 --reads 2000000 --overlap 1 --no-cpu-baseline --no-e2e`; per launch = per batch of 1 M reads)"}
     json.dump(out, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
     print(out)

@@ -36,6 +36,50 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *tab, uint64_t nblk,
 	if (acc == 0x1234567) atomicAdd(sink, acc);
 }
 
+// the same gathers, loaded quad-cooperatively: in round r the four lanes of a quad read the four 16-byte quarters of quad-lane r's
+// block with ONE instruction (a wavefront instruction then touches 16 cache lines instead of 64)
+template <int K>
+__global__ __launch_bounds__(256) void k_gather_coop(const uint4 *tab, uint64_t nblk, int steps, unsigned long long *sink)
+{
+	uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+	const int ql = threadIdx.x & 3;
+	uint64_t s[K];
+	for (int k = 0; k < K; ++k) s[k] = (tid * K + k) * 0x9E3779B97F4A7C15ull + 12345;
+	uint64_t acc = 0;
+	for (int it = 0; it < steps; ++it) {
+		uint4 v[K][4];
+		for (int k = 0; k < K; ++k) {
+			s[k] ^= s[k] >> 29; s[k] *= 0xBF58476D1CE4E5B9ull; s[k] ^= s[k] >> 32;
+			const uint64_t mine = (s[k] % nblk) * 4;
+			for (int r = 0; r < 4; ++r) {
+				const uint64_t blk = __shfl(mine, (threadIdx.x & ~3) + r);   // quad-lane r's block index
+				v[k][r] = tab[blk + ql];
+			}
+		}
+		for (int k = 0; k < K; ++k) {
+			uint64_t h = (uint64_t)(v[k][0].x ^ v[k][1].y ^ v[k][2].z ^ v[k][3].w);
+			s[k] += h; acc += h;
+		}
+	}
+	if (acc == 0x1234567) atomicAdd(sink, acc);
+}
+template <int K>
+static double run_coop(const uint4 *tab, uint64_t nblk, int waves_per_cu, int steps, unsigned long long *sink, const char *what)
+{
+	int blocks = 256 * waves_per_cu / 4;
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL((k_gather_coop<K>), dim3(blocks), dim3(256), 0, 0, tab, nblk, steps / 4, sink);
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL((k_gather_coop<K>), dim3(blocks), dim3(256), 0, 0, tab, nblk, steps, sink);
+	hipEventRecord(e1, 0); hipEventSynchronize(e1);
+	float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+	double lines = (double)blocks * 256 * K * steps;
+	printf("%-28s table %6.0f MB  waves/CU %2d  K %d          : %8.3f ms  %7.2f G gathers/s  %7.1f GB/s (64 B each)\n", what,
+	       nblk * 64 / 1e6, waves_per_cu, K, ms, lines / ms / 1e6, lines * 64 / ms / 1e6);
+	fflush(stdout);
+	return lines * 64 / ms / 1e6;
+}
+
 __global__ __launch_bounds__(256) void k_copy(const uint4 *src, uint4 *dst, size_t n)
 {
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -92,6 +136,10 @@ int main(int argc, char **argv)
 	}
 	for (uint64_t mb : { 64ull, 512ull, 3072ull, 8192ull }) {
 		uint64_t nblk = mb * (1ull << 20) / 64;
+		run_coop<1>(tab, nblk, 16, 400, sink, "quad-cooperative, 1/lane");
+		run_coop<2>(tab, nblk, 16, 400, sink, "quad-cooperative, 2/lane");
+		run_coop<2>(tab, nblk, 32, 400, sink, "quad-cooperative, 2/lane");
+		run_coop<4>(tab, nblk, 16, 200, sink, "quad-cooperative, 4/lane");
 		run<1, 0>(tab, nblk, 16, 400, scratch, per_lane, sink, "dependent gather");
 		run<2, 0>(tab, nblk, 16, 400, scratch, per_lane, sink, "2 gathers/lane/step");
 		run<2, 0>(tab, nblk, 32, 400, scratch, per_lane, sink, "2 gathers/lane/step");
