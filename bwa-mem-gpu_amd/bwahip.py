@@ -98,6 +98,10 @@ def lib():
     L.bwahip_rccl_unique_id.argtypes = [vp]
     L.bwahip_init_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.bwahip_ctx_clone.argtypes = [vp, C.POINTER(vp)]
+    L.bwahip_fastq_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.bwahip_fastq_next.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.POINTER(Seq)), C.POINTER(C.c_int)]
+    L.bwahip_fastq_close.argtypes = [vp]
+    L.bwahip_fastq_close.restype = None
     L.bwahip_ctx_set_rg_id.argtypes = [vp, C.c_char_p]
     L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
@@ -272,6 +276,18 @@ class Context:
             libc.free(C.cast(arr[i].sam, C.c_void_p))
         return out
 
+    def process_seqs_array(self, arr, n, opt=None, n_processed=0, pes0=None):
+        """bwahip_process_seqs on a bseq1_t array (e.g. a FastqReader batch); returns the batch's SAM text (bwahip_seqs_take_sam)."""
+        opt = opt or default_opt()
+        _check(lib().bwahip_process_seqs(self._h, C.byref(opt), n_processed, n, arr, pes0), "bwahip_process_seqs")
+        out, ln = C.c_void_p(), C.c_int64()
+        _check(lib().bwahip_seqs_take_sam(arr, n, C.byref(out), C.byref(ln)), "bwahip_seqs_take_sam")
+        sam = C.string_at(out, ln.value)
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(out)
+        return sam
+
     def last_pe_stats(self):
         """(pestat[4] as dicts, mate-rescue alignments run on the GPU, regions they added) of the last PE batch."""
         pes = (PeStat * 4)()
@@ -376,6 +392,31 @@ class Context:
 
 
 # ---------------------------------------------------------------- tooling wrappers (synthetic data, index build)
+class FastqReader:
+    """bwahip_fastq_*: batches of a FASTA/FASTQ file (pair), plain or gzip, as bseq_read (bwa.c:191) cuts them."""
+
+    def __init__(self, path1, path2=None):
+        self._h = C.c_void_p()
+        _check(lib().bwahip_fastq_open(os.fsencode(path1), os.fsencode(path2) if path2 else None, C.byref(self._h)), "bwahip_fastq_open")
+
+    def next(self, chunk_bases, keep_comments=False):
+        """-> (pointer to the bseq1_t array owned by the reader, n); n == 0 at the end of the input."""
+        arr, n = C.POINTER(Seq)(), C.c_int()
+        _check(lib().bwahip_fastq_next(self._h, chunk_bases, 1 if keep_comments else 0, C.byref(arr), C.byref(n)), "bwahip_fastq_next")
+        return arr, n.value
+
+    def close(self):
+        if self._h:
+            lib().bwahip_fastq_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def _tool(name):
     path = os.path.join(TOOLS, name)
     if not os.path.exists(path):

@@ -159,6 +159,18 @@ typedef struct { uint64_t x[3], info; } bwahip_intv_t;              /* bwtintv_t
 
 typedef struct bwahip_ctx bwahip_ctx;
 
+/* ---- reading FASTA/FASTQ (plain or gzip) into batches: bseq_read (bwa.c:191) / kseq_read (kseq.h:176) ----------------------
+ * One reader thread per file inflates and parses ahead of the caller, so the next batch is read while the GPU works on the
+ * current one.  path2 != NULL: the mates' file, batches come interleaved (read i of file 1, read i of file 2); "-" = stdin. */
+typedef struct bwahip_fastq bwahip_fastq;
+int  bwahip_fastq_open(const char *path1, const char *path2, bwahip_fastq **out);
+/* Next batch: reads until it holds at least chunk_bases bases and an even number of reads (bwa.c:216; `bwa mem -K`).  *n = 0 at
+ * the end of the input.  name/comment/seq/qual of (*seqs)[i] point into the reader's memory and stay valid until the next call
+ * or bwahip_fastq_close -- unlike bseq_read's they are NOT the caller's to free; seqs[i].sam (set by bwahip_process_seqs) is.
+ * keep_comments = 0 drops FASTQ comments (stock behaviour without -C).  Names lose a trailing "/[0-9]" (bwa.c:73). */
+int  bwahip_fastq_next(bwahip_fastq *r, int64_t chunk_bases, int keep_comments, bwahip_seq_t **seqs, int *n);
+void bwahip_fastq_close(bwahip_fastq *r);
+
 /* ---- lifetime ------------------------------------------------------------
  * bwahip_init replaces newProcess()/transferIndex() (cuda/streams.cu:8,164): it copies the three
  * index arrays (bwt, sa, pac) and the contig table into HBM of HIP device `device` and builds the

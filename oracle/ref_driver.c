@@ -410,6 +410,33 @@ static int main_katalign(int argc, char **argv)
 	return 0;
 }
 
+/* readfq <chunk_bases> <in1> [in2]: the batches the reference's bseq_read (bwa.c:191) cuts, one record per line as
+ * name TAB comment-or-* TAB seq TAB qual-or-*, a line "#batch <n>" in front of every batch -- golden vectors for the product's
+ * FASTA/FASTQ reader (csrc/fastq_reader.cpp) */
+static int main_readfq(int argc, char **argv)
+{
+	gzFile f1, f2 = 0;
+	kseq_t *ks, *ks2 = 0;
+	bseq1_t *seqs;
+	int n, i, chunk;
+	if (argc < 3) return 1;
+	chunk = atoi(argv[1]);
+	f1 = gzopen(argv[2], "r"); ks = kseq_init(f1);
+	if (argc > 3) { f2 = gzopen(argv[3], "r"); ks2 = kseq_init(f2); }
+	while ((seqs = bseq_read(chunk, &n, ks, ks2)) != 0) {
+		printf("#batch %d\n", n);
+		for (i = 0; i < n; ++i) {
+			printf("%s\t%s\t%s\t%s\n", seqs[i].name, seqs[i].comment ? seqs[i].comment : "*", seqs[i].seq, seqs[i].qual ? seqs[i].qual : "*");
+			free(seqs[i].name); free(seqs[i].comment); free(seqs[i].seq); free(seqs[i].qual);
+		}
+		free(seqs);
+		if (n == 0) break;
+	}
+	kseq_destroy(ks); gzclose(f1);
+	if (ks2) { kseq_destroy(ks2); gzclose(f2); }
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 2) {
@@ -422,6 +449,7 @@ int main(int argc, char **argv)
 	if (strcmp(argv[1], "katfm") == 0) return main_katfm(argc - 1, argv + 1);
 	if (strcmp(argv[1], "katksw") == 0) return main_katksw(argc - 1, argv + 1);
 	if (strcmp(argv[1], "katalign") == 0) return main_katalign(argc - 1, argv + 1);
+	if (strcmp(argv[1], "readfq") == 0) return main_readfq(argc - 1, argv + 1);
 	fprintf(stderr, "unknown sub-command '%s'\n", argv[1]);
 	return 1;
 }

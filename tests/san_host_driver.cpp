@@ -8,9 +8,8 @@
 extern "C" {
 #include "../oracle/ora.h"
 }
-#include <fstream>
+#include <limits.h>
 int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);   // host_final.cpp
-#include <iostream>
 
 struct bwahip_ctx { HostIndex host; ora_index_t *oidx; };
 
@@ -43,20 +42,6 @@ int bwahip_align_batch(bwahip_ctx *c, const bwahip_opt_t *opt, int n, bwahip_seq
 	return 0;
 }
 
-struct Fq { std::vector<std::string> name, seq, qual; };
-static bool read_fq(const char *path, Fq &f)
-{
-	std::ifstream in(path);
-	if (!in) return false;
-	std::string h, s, p, q;
-	while (std::getline(in, h) && std::getline(in, s) && std::getline(in, p) && std::getline(in, q)) {
-		std::string nm = h.substr(1, h.find_first_of(" \t") == std::string::npos ? std::string::npos : h.find_first_of(" \t") - 1);
-		if (nm.size() > 2 && nm[nm.size() - 2] == '/' && (nm.back() == '1' || nm.back() == '2')) nm.resize(nm.size() - 2);   // bwa.c:73-77
-		f.name.push_back(nm); f.seq.push_back(s); f.qual.push_back(q);
-	}
-	return true;
-}
-
 int main(int argc, char **argv)
 {
 	bwahip_opt_t opt;
@@ -64,32 +49,41 @@ int main(int argc, char **argv)
 	ora_opt_init(&oo);
 	memcpy(&opt, &oo, sizeof opt);
 	int ai = 1;
+	long long dump_chunk = 0;                                  // -d CHUNK: only read the input and print the batches (format of `bwaref readfq`)
 	opt.n_threads = 3;
 	for (; ai < argc && argv[ai][0] == '-'; ++ai) {
 		if (!strcmp(argv[ai], "-p")) opt.flag |= BWAHIP_F_PE;
 		else if (!strcmp(argv[ai], "-a")) opt.flag |= BWAHIP_F_ALL;
+		else if (!strcmp(argv[ai], "-d") && ai + 1 < argc) dump_chunk = atoll(argv[++ai]);
 		else if (!strcmp(argv[ai], "-t") && ai + 1 < argc) opt.n_threads = atoi(argv[++ai]);
 		else { fprintf(stderr, "unknown option %s\n", argv[ai]); return 2; }
+	}
+	if (dump_chunk > 0 && argc - ai >= 1) {
+		bwahip_fastq *rd = nullptr;
+		if (bwahip_fastq_open(argv[ai], argc - ai > 1 ? argv[ai + 1] : nullptr, &rd)) return 1;
+		for (;;) {
+			bwahip_seq_t *sp = nullptr; int n = 0;
+			if (bwahip_fastq_next(rd, dump_chunk, 1, &sp, &n)) return 1;
+			if (n == 0) break;
+			printf("#batch %d\n", n);
+			for (int i = 0; i < n; ++i) printf("%s\t%s\t%s\t%s\n", sp[i].name, sp[i].comment ? sp[i].comment : "*", sp[i].seq, sp[i].qual ? sp[i].qual : "*");
+		}
+		bwahip_fastq_close(rd);
+		return 0;
 	}
 	if (argc - ai < 2) { fprintf(stderr, "usage: san_host_driver [-p] [-a] [-t N] <prefix> <reads.fq> [mates.fq]\n"); return 2; }
 	bwahip_ctx ctx;
 	if (bwahip_load_index_files(argv[ai], &ctx.host)) { fprintf(stderr, "index load failed\n"); return 1; }
 	ctx.oidx = ora_index_load(argv[ai]);
 	if (!ctx.oidx) { fprintf(stderr, "oracle index load failed\n"); return 1; }
-	Fq f[2];
+	// the product's own FASTQ reader (csrc/fastq_reader.cpp) supplies the batch: it runs under the sanitizers too
 	const int n_files = argc - ai - 1;
-	for (int k = 0; k < n_files && k < 2; ++k) if (!read_fq(argv[ai + 1 + k], f[k])) { fprintf(stderr, "cannot read %s\n", argv[ai + 1 + k]); return 1; }
+	bwahip_fastq *rd = nullptr;
+	if (bwahip_fastq_open(argv[ai + 1], n_files == 2 ? argv[ai + 2] : nullptr, &rd)) { fprintf(stderr, "cannot read the input\n"); return 1; }
 	if (n_files == 2) opt.flag |= BWAHIP_F_PE;
-	const bool two = n_files == 2;
-	const int n = (int)f[0].name.size() * (two ? 2 : 1);
-	std::vector<bwahip_seq_t> seqs(n);
-	for (int i = 0; i < n; ++i) {
-		const Fq &src = two ? f[i & 1] : f[0];
-		const int j = two ? i >> 1 : i;
-		memset(&seqs[i], 0, sizeof seqs[i]);
-		seqs[i].name = strdup(src.name[j].c_str()); seqs[i].seq = strdup(src.seq[j].c_str()); seqs[i].qual = strdup(src.qual[j].c_str());
-		seqs[i].l_seq = (int)src.seq[j].size(); seqs[i].id = i;
-	}
+	bwahip_seq_t *sp = nullptr; int n = 0;
+	if (bwahip_fastq_next(rd, INT64_MAX / 2, 0, &sp, &n)) return 1;
+	std::vector<bwahip_seq_t> seqs(sp, sp + n);
 	// two batches with their true n_processed (hash_64 tie-breaks, bwamem.c:1204,1210), as the reference cuts a long input
 	const int half = (opt.flag & BWAHIP_F_PE) ? n : (n / 2) & ~1;      // PE: one batch (mem_pestat is per batch, and the golden run had one)
 	int rc = bwahip_process_seqs_host(&ctx, &opt, 0, half, seqs.data(), nullptr);
@@ -99,7 +93,7 @@ int main(int argc, char **argv)
 	if (bwahip_seqs_take_sam(seqs.data(), n, &sam, &len)) return 1;
 	fwrite(sam, 1, (size_t)len, stdout);
 	free(sam);
-	for (auto &s : seqs) { free(s.name); free(s.seq); free(s.qual); }
+	bwahip_fastq_close(rd);
 	bwahip_free_host_index(&ctx.host);
 	ora_index_destroy(ctx.oidx);
 	return 0;

@@ -229,3 +229,31 @@ def test_comments_and_read_group(ctx, small_index, tmp_path):
         assert got == body(want)
     finally:
         ctx.set_rg_id(None)
+
+
+def test_files_through_the_product_reader(ctx, small_index, tmp_path):
+    """FASTQ files (one of them gzipped) -> bwahip_fastq_* -> bwahip_process_seqs, batch by batch with -K 30000, vs the CPU path
+    reading the same files with the same -K: the reader's batches, n_processed and the SAM must all line up (SE and PE)."""
+    import gzip
+    fq1, fq2 = str(tmp_path / "f_1.fq"), str(tmp_path / "f_2.fq")
+    bw.make_reads(small_index["fa"], fq1, fq2, 1500, 150, 10000, 2000, 500, 181, 20000)
+    gz2 = fq2 + ".gz"
+    gzip.open(gz2, "wb").write(open(fq2, "rb").read())
+    for files in ((fq1,), (fq1, gz2)):
+        opt = bw.default_opt()
+        opt.n_threads = 4
+        if len(files) == 2:
+            opt.flag |= 0x2
+        want = subprocess.run([common.ORACLE, "mem", "-t", "4", "-K", "30000", small_index["prefix"], *files], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        got, n_processed, n_batches = [], 0, 0
+        with bw.FastqReader(*files) as rd:
+            while True:
+                arr, n = rd.next(30000)
+                if n == 0:
+                    break
+                got.append(ctx.process_seqs_array(arr, n, opt, n_processed=n_processed))
+                n_processed += n
+                n_batches += 1
+        assert n_batches >= 7 and n_processed == 1500 * len(files)
+        body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
+        assert b"".join(got) == body(want)

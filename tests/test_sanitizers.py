@@ -1,5 +1,5 @@
 """CPU builds under AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are not available on the pool):
-  * the product's host-side code: csrc/index_io.cpp + csrc/host_final.cpp (driven by tests/san_host_driver.cpp, where the CPU
+  * the product's host-side code: csrc/index_io.cpp + csrc/host_final.cpp + csrc/fastq_reader.cpp (driven by tests/san_host_driver.cpp, where the CPU
     oracle stands in for the one GPU call those files make) and tools/mkindex.cpp;
   * the oracle itself (oracle/ora_*.c + main_oracle.c).
 Every run must finish without a sanitizer report (-fno-sanitize-recover: any report aborts) AND reproduce the golden
@@ -27,7 +27,7 @@ def san(tmp_path_factory):
     for f in ora + ["main_oracle.c"]:
         jobs.append(["gcc", *SAN, "-c", os.path.join(ROOT, "oracle", f), "-o", os.path.join(d, f[:-2] + ".o")])
     hipinc = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-std=c++17", "-Wno-unused-result"]   # hip_runtime.h as plain host C++: types only
-    for src, obj in ((os.path.join(CSRC, "index_io.cpp"), "index_io.o"), (os.path.join(CSRC, "host_final.cpp"), "host_final.o"),
+    for src, obj in ((os.path.join(CSRC, "index_io.cpp"), "index_io.o"), (os.path.join(CSRC, "host_final.cpp"), "host_final.o"), (os.path.join(CSRC, "fastq_reader.cpp"), "fastq_reader.o"),
                      (os.path.join(ROOT, "tests", "san_host_driver.cpp"), "driver.o")):
         jobs.append(["g++", *SAN, *hipinc, "-c", src, "-o", os.path.join(d, obj)])
     jobs.append(["g++", *SAN, "-std=c++17", "-fopenmp", "-o", os.path.join(d, "mkindex"), os.path.join(ROOT, "bwa-mem-gpu_amd", "tools", "mkindex.cpp")])
@@ -38,7 +38,7 @@ def san(tmp_path_factory):
     link = ["-fsanitize=address,undefined", "-lm", "-lz", "-lpthread"]
     subprocess.check_call(["gcc", "-o", os.path.join(d, "bwa_oracle"), os.path.join(d, "main_oracle.o"), *oo, *link])
     subprocess.check_call(["g++", "-o", os.path.join(d, "host_driver"), os.path.join(d, "driver.o"), os.path.join(d, "index_io.o"),
-                           os.path.join(d, "host_final.o"), *oo, *link])
+                           os.path.join(d, "host_final.o"), os.path.join(d, "fastq_reader.o"), *oo, *link])
     fa = os.path.join(d, "g60k.fa")
     open(fa, "wb").write(gzip.open(os.path.join(G, "g60k.fa.gz")).read())
     open(os.path.join(d, "g60k.alt"), "wb").write(open(os.path.join(G, "g60k.alt"), "rb").read())
@@ -75,3 +75,13 @@ def test_oracle_clean_and_identical_to_reference_sam(san, name, extra, fqs):
     test_mkindex_clean_and_identical_to_reference_index(san)
     got = _run([os.path.join(san, "bwa_oracle"), "mem", *extra, os.path.join(san, "g60k"), *[os.path.join(san, f) for f in fqs]])
     assert got == gzip.open(os.path.join(G, name + ".sam.gz")).read()
+
+
+@pytest.mark.parametrize("want,fqs,chunk", [("cases_1.se.txt", ["cases_1.fq"], 100000), ("cases.pe.txt", ["cases_1.fq", "cases_2.fq"], 100000),
+                                            ("pairs.pe3000.txt", ["pairs_1.fq", "pairs_2.fq.gz"], 3000), ("pairs.se777.txt", ["pairs_1.fq"], 777)])
+def test_fastq_reader_clean_and_identical_to_reference_bseq_read(san, want, fqs, chunk):
+    """csrc/fastq_reader.cpp under ASan/UBSan on the hand-made FASTA/FASTQ cases (CRLF, multi-line, truncated last record, fewer mates,
+    gzip, -K chunking) against the batches the reference's bseq_read cut (tests/golden/fastq)."""
+    F = os.path.join(G, "fastq")
+    got = _run([os.path.join(san, "host_driver"), "-d", str(chunk), *[os.path.join(F, f) for f in fqs]])
+    assert got == open(os.path.join(F, want), "rb").read()
