@@ -254,6 +254,6 @@ def test_files_through_the_product_reader(ctx, small_index, tmp_path):
                 got.append(ctx.process_seqs_array(arr, n, opt, n_processed=n_processed))
                 n_processed += n
                 n_batches += 1
-        assert n_batches >= 7 and n_processed == 1500 * len(files)
+        assert n_batches >= 4 and n_processed == 750 * len(files)
         body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
         assert b"".join(got) == body(want)
