@@ -38,6 +38,12 @@ __device__ int approx_mapq_se(const DevOpt &o, const double *logtab, const FinRe
 // the ones listed in an XA tag.  z: 2n ints of scratch.  Wavefront-collective; counts are returned in every lane.
 __device__ void select_records(const DevOpt &opt, int n, const FinReg *f, uint8_t *need, int *owner, int *z, int l, int &n_task, int &n_rec)
 {
+	if (n == 1) {                                               // the common case, without the list machinery: a lone region is nobody's secondary
+		const int rec = f[0].score >= opt.T ? 1 : 0;
+		if (l == 0) { need[0] = (uint8_t)(rec ? NEED_REC : 0); owner[0] = -1; }
+		n_task = n_rec = rec;
+		return;
+	}
 	// ---- selection: mem_gen_alt's XA membership (bwamem_extra.c:116-145) and mem_reg2sam's record filter (bwamem.c:1025-1031)
 	int *cnt = z, *has_alt = z + n;                             // z is free now (2n of the 4n scratch ints)
 	for (int i = l; i < n; i += 64) { cnt[i] = 0; has_alt[i] = 0; need[i] = 0; owner[i] = -1; }

@@ -106,6 +106,26 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 	if (n == 0) { if (l == 0) { a.n_pri[r] = 0; if (PLAN) { a.task_n[r] = 0; a.rec_n[r] = 0; } } return; }
 	// id of region i for the tie-breaking hash (bwamem.c:534): SE n_processed + read; PE ((n_processed>>1) + pair)<<1 | end
 	const uint64_t id = (opt.flag & BWAHIP_F_PE) ? ((((uint64_t)a.n_processed >> 1) + (uint64_t)(r >> 1)) << 1 | (uint64_t)(r & 1)) : (uint64_t)a.n_processed + (uint64_t)r;
+	if (n == 1) {
+		// a read with one region (most reads): what the code below does to it, written out -- it sorts to itself, overlaps nothing,
+		// and ends with secondary = secondary_all = -1, sub = 0 whether it lies on an ALT contig or not (bwamem.c:528-565)
+		if (l == 0) {
+			const DevReg p = a.regs[rb0];
+			FinReg q;
+			q.rb = p.rb; q.re = p.re; q.hash = hash_64(id); q.frac_rep = p.frac_rep;
+			q.qb = p.qb; q.qe = p.qe; q.rid = p.rid; q.score = p.score; q.truesc = p.truesc; q.sub = 0; q.alt_sc = 0; q.csub = p.csub;
+			q.sub_n = p.sub_n; q.w = p.w; q.seedcov = p.seedcov; q.secondary = -1; q.secondary_all = -1; q.seedlen0 = p.seedlen0;
+			q.n_comp = p.n_comp; q.is_alt = p.is_alt; q.pad = 0;
+			f[0] = q;
+			a.n_pri[r] = p.is_alt ? 0 : 1;
+			if (PLAN) {
+				const int rec = q.score >= opt.T ? 1 : 0;
+				a.need[rb0] = (uint8_t)(rec ? NEED_REC : 0); a.xa_owner[rb0] = -1;
+				a.task_n[r] = rec; a.rec_n[r] = rec;
+			}
+		}
+		return;
+	}
 	int n_pri = 0;
 	for (int base = 0; base < n; base += 64) {
 		const int i = base + l;
