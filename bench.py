@@ -299,6 +299,40 @@ def main():
             t_e2e = float(tm.item())
         e2e = {"reads_per_s": n_s * world / t_e2e, "seconds": t_e2e, "reads": n_s * world, "host_threads_per_gpu": opt.n_threads}
         log(f"e2e: {n_s} reads through bwahip_process_seqs in {t_e2e:.3f}s with {opt.n_threads} host threads")
+        if world == 1:
+            # the same batch with the SAM handed over in one piece (bwahip_process_seqs_text: what a caller whose output step is one fwrite
+            # uses), and two such batches in flight on two contexts (bwahip_ctx_clone), each caller with half of the host threads
+            import zlib
+            want = (len(sam_gpu), zlib.crc32(sam_gpu))
+            one = tp.bulk_caller(bw, ctx, opt, names_host[:n_s], reads[:n_s], one_piece=True)
+            _, ln, crc = one(check=True)
+            assert (ln, crc) == want, "bwahip_process_seqs_text: SAM differs from bwahip_process_seqs'"
+            e2e["one_piece_reads_per_s"] = n_s / min(one()[0] for _ in range(3))
+            log(f"e2e, SAM in one piece: {e2e['one_piece_reads_per_s']:.0f} reads/s")
+            if args.overlap > 1:
+                c2 = ctx.clone()
+                o2 = bw.Opt.from_buffer_copy(opt)
+                o2.n_threads = max(1, opt.n_threads // 2)
+                callers = [tp.bulk_caller(bw, cx, o2, names_host[:n_s], reads[:n_s], one_piece=True) for cx in (ctx, c2)]
+                for c in callers:
+                    _, ln, crc = c(check=True)
+                    assert (ln, crc) == want, "SAM of a batch differs on the second context"
+                lens = [[], []]
+
+                def caller(t):
+                    for _ in range(4):
+                        lens[t].append(callers[t]()[1])
+                th = [threading.Thread(target=caller, args=(t,)) for t in range(2)]
+                t0 = time.time()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                t2 = time.time() - t0
+                c2.close()
+                assert all(v == want[0] for v in lens[0] + lens[1])
+                e2e["two_in_flight_reads_per_s"] = 8 * n_s / t2
+                log(f"e2e, two batches in flight: {8 * n_s} reads in {t2:.3f}s")
 
     if rank == 0:
         n_launch = len(kms)
@@ -350,6 +384,13 @@ def main():
             out["value_e2e"] = round(e2e["reads_per_s"], 1)
             out["e2e"] = {"what": "bwahip_process_seqs: host bseq1_t arrays in (ASCII reads, names, qualities) -> seqs[i].sam text out, one batch per GPU, PCIe and host work included",
                           "reads": e2e["reads"], "seconds": round(e2e["seconds"], 4), "host_threads_per_gpu": e2e["host_threads_per_gpu"]}
+            if "one_piece_reads_per_s" in e2e:
+                out["e2e"]["one_piece_reads_per_s"] = round(e2e["one_piece_reads_per_s"], 1)
+                out["e2e"]["one_piece_what"] = "bwahip_process_seqs_text: the same call with the batch's SAM handed over as one buffer (no malloc per read); same bytes"
+            if "two_in_flight_reads_per_s" in e2e:
+                out["e2e"]["two_in_flight_reads_per_s"] = round(e2e["two_in_flight_reads_per_s"], 1)
+                out["e2e"]["two_in_flight_what"] = ("two caller threads, each with its own context (bwahip_ctx_clone: shared index) and half of the host threads, "
+                                                    "4 batches each back to back through bwahip_process_seqs_text")
         # HBM traffic of the same kernel from the committed PMC passes of this very command (counters cannot be read from
         # inside the process); quoted only when the per-launch workload (one batch) AND the kernel sources are the ones the
         # counters were collected on

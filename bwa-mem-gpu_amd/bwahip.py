@@ -98,6 +98,7 @@ def lib():
     L.bwahip_rccl_unique_id.argtypes = [vp]
     L.bwahip_init_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.bwahip_ctx_clone.argtypes = [vp, C.POINTER(vp)]
+    L.bwahip_process_seqs_text.argtypes = [vp, C.POINTER(Opt), C.c_int64, C.c_int, C.POINTER(Seq), C.c_void_p, C.POINTER(C.c_char_p), i64p, C.POINTER(i64p)]
     L.bwahip_fastq_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.bwahip_fastq_next.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.POINTER(Seq)), C.POINTER(C.c_int)]
     L.bwahip_fastq_close.argtypes = [vp]
@@ -287,6 +288,14 @@ class Context:
         libc.free.argtypes = [C.c_void_p]
         libc.free(out)
         return sam
+
+    def process_seqs_text_array(self, arr, n, opt=None, n_processed=0, pes0=None, want_offsets=False):
+        """bwahip_process_seqs_text on a bseq1_t array: the batch's SAM as one bytes object (copied out of the context's buffer)."""
+        opt = opt or default_opt()
+        sam, ln, off = C.c_char_p(), C.c_int64(), C.POINTER(C.c_int64)()
+        _check(lib().bwahip_process_seqs_text(self._h, C.byref(opt), n_processed, n, arr, pes0, C.byref(sam), C.byref(ln), C.byref(off)), "bwahip_process_seqs_text")
+        text = C.string_at(sam, ln.value)
+        return (text, [off[i] for i in range(n + 1)]) if want_offsets else text
 
     def last_pe_stats(self):
         """(pestat[4] as dicts, mate-rescue alignments run on the GPU, regions they added) of the last PE batch."""

@@ -76,6 +76,7 @@ struct BatchText {
 
 struct bwahip_ctx {
 	BatchText batch_text;
+	std::vector<int64_t> h_sam_off;      // offsets of the reads' SAM text in h_sam (bwahip_process_seqs / _text)
 	bool external_index = false;
 	bool index_resident = false;         // d_bwt / d_sa / d_pac were filled before ctx_setup (bwahip_init_rccl)
 	Knobs knobs;

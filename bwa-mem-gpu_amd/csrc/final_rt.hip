@@ -403,12 +403,18 @@ static int stage_text(bwahip_ctx *c, int nt, int n, bwahip_seq_t *seqs, const Ba
 	return 0;
 }
 
-extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
+// text != nullptr: the batch's SAM stays one piece (in the context's pinned buffer) instead of being cut into per-read strings
+static int process_seqs_impl(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0,
+                             const char **text_out, int64_t *len_out, const int64_t **off_out)
 {
 	if (!ctx || !opt || n < 0 || (n && !seqs)) return BWAHIP_EINVAL;
 	const bool pe = (opt->flag & BWAHIP_F_PE) != 0;
 	if (pe && (n & 1)) return BWAHIP_EINVAL;
-	if (!ctx->knobs.gpu_final || (pe && !ctx->knobs.gpu_pair)) return bwahip_process_seqs_host(ctx, opt, n_processed, n, seqs, pes0);
+	if (text_out) { *text_out = ""; *len_out = 0; if (off_out) *off_out = nullptr; }
+	if (!ctx->knobs.gpu_final || (pe && !ctx->knobs.gpu_pair)) {
+		if (text_out) return BWAHIP_EINVAL;                       // the one-piece output exists on the GPU path only
+		return bwahip_process_seqs_host(ctx, opt, n_processed, n, seqs, pes0);
+	}
 	if (pe) for (int i = 0; i < n; i += 2) if (strcmp(seqs[i].name, seqs[i + 1].name) != 0) { fprintf(stderr, "[bwahip] paired reads have different names\n"); return BWAHIP_EINVAL; }   // err_fatal in the reference (bwamem_pair.c:386)
 	if (n == 0) return 0;
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -432,10 +438,31 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 	// SAM text back through the pinned buffer, on the context's stream (a non-blocking stream: a plain hipMemcpy would not wait
 	// for the SAM kernel), in slices of reads: while slice k+1 travels, the host threads cut slice k into one malloc()ed string
 	// per read, which is what the reference's contract wants (bwamem.c:1054)
-	std::vector<int64_t> soff(n + 1);
+	std::vector<int64_t> &soff = ctx->h_sam_off;
+	soff.resize((size_t)n + 1);
 	if ((rc = ctx->h_sam.ensure((size_t)ctx->total_sam + 1))) return rc;
 	char *text = (char*)ctx->h_sam.p;
 	HIP_TRY(hipMemcpyAsync(soff.data(), ctx->d_sam_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+	if (text_out) {                                               // one piece: a single copy, no per-read strings
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		const double t3 = now();
+		{
+			const size_t tot = (size_t)ctx->total_sam, piece = ((tot + 7) / 8 + 4095) & ~(size_t)4095;
+			int k = 0;
+			for (size_t at = 0; at < tot; at += piece, ++k)
+				HIP_TRY(hipMemcpyAsync(text + at, (const char*)ctx->d_sam.p + at, tot - at < piece ? tot - at : piece, hipMemcpyDeviceToHost, (k & 1) ? ctx->stream_copy : ctx->stream));
+			HIP_TRY(hipStreamSynchronize(ctx->stream_copy));
+			HIP_TRY(hipStreamSynchronize(ctx->stream));
+		}
+		text[ctx->total_sam] = 0;
+		*text_out = text; *len_out = ctx->total_sam; if (off_out) *off_out = soff.data();
+		const double t4 = now();
+		par_for_chunks(n, nt, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) seqs[i].sam = nullptr; });
+		if (verbose || ctx->knobs.e2e_log)
+			fprintf(stderr, "[bwahip] process_seqs_text %d reads: codes gather+upload %.1f ms, hot path (text upload beside it) %.1f ms, finalisation+SAM on GPU %.1f ms, download %.1f ms (%lld bytes), rest %.1f ms\n",
+			        n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (long long)ctx->total_sam, (now() - t4) * 1e3);
+		return 0;
+	}
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	constexpr int SLICES = 8;
 	int n_sl = 0;
@@ -472,6 +499,21 @@ extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int
 		        n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)ctx->total_sam, (now() - t3) * 1e3);
 	if (hip_bad) return BWAHIP_ENODEV;
 	return oom ? BWAHIP_ENOMEM : 0;
+}
+
+extern "C" int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
+{
+	return process_seqs_impl(ctx, opt, n_processed, n, seqs, pes0, nullptr, nullptr, nullptr);
+}
+
+// The same work with the batch's SAM handed over in one piece -- for a caller whose output step is one fwrite (fastmap.c prints
+// seqs[i].sam read by read): no malloc per read, no second copy.  *sam: NUL-terminated text of the whole batch in read order, *off
+// (optional): n + 1 offsets, read i's records are sam[off[i] .. off[i+1]).  Both live in the context and stay valid until its next call.
+extern "C" int bwahip_process_seqs_text(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0,
+                                        const char **sam, int64_t *sam_len, const int64_t **off)
+{
+	if (!sam || !sam_len) return BWAHIP_EINVAL;
+	return process_seqs_impl(ctx, opt, n_processed, n, seqs, pes0, sam, sam_len, off);
 }
 
 // Insert-size statistics (mem_pestat_t x 4: FF, FR, RF, RR) and mate-rescue counters ([0] Smith-Waterman alignments run on

@@ -168,6 +168,52 @@ def process_seqs_bulk(bw, ctx, opt, names, reads, qual=b"I", n_processed=0, pes0
     return dt, sam
 
 
+def bulk_caller(bw, ctx, opt, names, reads, qual=b"I", one_piece=False):
+    """A prepared bseq1_t array + a function that pushes it through bwahip_process_seqs once and returns (seconds, SAM length, crc32 of the
+    SAM): the caller's side of a batch without any per-batch Python work, for timing several callers at once."""
+    import ctypes as C
+    import time
+    import zlib
+    n, rl = reads.shape
+    pristine = np.ascontiguousarray(reads)
+    seqbuf = pristine.copy()
+    names = np.ascontiguousarray(names)
+    qbuf = np.frombuffer(qual * rl + b"\0", dtype=np.uint8).copy()
+    arr = np.zeros(n, dtype=SEQ_DTYPE)
+    arr["l_seq"] = rl
+    arr["id"] = np.arange(n)
+    arr["name"] = names.ctypes.data + np.arange(n, dtype=np.uint64) * names.shape[1]
+    arr["seq"] = seqbuf.ctypes.data + np.arange(n, dtype=np.uint64) * rl
+    arr["qual"] = qbuf.ctypes.data
+    L = bw.lib()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    keep = (pristine, seqbuf, names, qbuf, arr)
+
+    def once(check=False):
+        np.copyto(seqbuf, pristine)                            # the library turns the bases into codes in place
+        t0 = time.time()
+        if one_piece:                                          # bwahip_process_seqs_text: the SAM stays in the context's buffer
+            sam, ln = C.c_char_p(), C.c_int64()
+            rc = L.bwahip_process_seqs_text(ctx._h, C.byref(opt), 0, n, C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), None, C.byref(sam), C.byref(ln), None)
+            dt = time.time() - t0
+            if rc != 0:
+                raise bw.BwahipError(f"bwahip_process_seqs_text failed: {bw.ERRORS.get(rc, rc)}")
+            crc = zlib.crc32(C.string_at(sam, ln.value)) if check else None
+            return dt, ln.value, crc
+        rc = L.bwahip_process_seqs(ctx._h, C.byref(opt), 0, n, C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), None)
+        if rc != 0:
+            raise bw.BwahipError(f"bwahip_process_seqs failed: {bw.ERRORS.get(rc, rc)}")
+        out, ln = C.c_void_p(), C.c_int64()
+        rc = L.bwahip_seqs_take_sam(C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), n, C.byref(out), C.byref(ln))
+        dt = time.time() - t0
+        crc = zlib.crc32((C.c_char * ln.value).from_address(out.value)) if check else None
+        libc.free(out)
+        return dt, ln.value, crc
+    once.keep = keep
+    return once
+
+
 # ------------------------------------------------------------------------------------------ index broadcast
 def load_index_arrays(prefix):
     """Read a stock index file set into numpy arrays + metadata (format: bwt.c:385-462, bntseq.c:65-211)."""

@@ -217,6 +217,11 @@ int bwahip_align_batch(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, bwahip_s
  * finalisation (mark primary, mapQ, CIGAR/NM/MD, SAM text; PE: insert-size stats, mate rescue,
  * pairing) with opt->n_threads host threads.  seqs[i].sam is malloc()ed, NUL terminated. */
 int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);
+/* The same work with the batch's SAM in one piece, for a caller whose output step is a single fwrite: *sam = NUL-terminated text
+ * of the whole batch in read order (*sam_len bytes), *off (may be NULL) = n + 1 offsets with read i's records at sam[off[i]..off[i+1]).
+ * Both point into the context and stay valid until the next call on it; seqs[i].sam is left NULL (no malloc per read). */
+int  bwahip_process_seqs_text(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs,
+                              const bwahip_pestat_t *pes0, const char **sam, int64_t *sam_len, const int64_t **off);
 
 /* Insert-size statistics (mem_pestat_t[4]: FF, FR, RF, RR; bwamem_pair.c:72) and mate-rescue counters ([0] local alignments
  * run, [1] regions added, [2] most alignments of one pair, [3] pairs that needed any; bwamem_pair.c:137) of the last

@@ -251,7 +251,12 @@ def test_files_through_the_product_reader(ctx, small_index, tmp_path):
                 arr, n = rd.next(30000)
                 if n == 0:
                     break
-                got.append(ctx.process_seqs_array(arr, n, opt, n_processed=n_processed))
+                text, off = ctx.process_seqs_text_array(arr, n, opt, n_processed=n_processed, want_offsets=True)   # SAM in one piece ...
+                assert off[0] == 0 and off[n] == len(text) and all(off[i] <= off[i + 1] for i in range(n))
+                assert all(text[off[i]:off[i + 1]].endswith(b"\n") for i in range(0, n, 97))
+                assert not arr[0].sam
+                got.append(ctx.process_seqs_array(arr, n, opt, n_processed=n_processed))                              # ... and per read: the same bytes
+                assert got[-1] == text
                 n_processed += n
                 n_batches += 1
         assert n_batches >= 4 and n_processed == 750 * len(files)
