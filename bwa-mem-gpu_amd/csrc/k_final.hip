@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_task_fill(FinLaunch a)
 // ===================================================================================================
 constexpr int CG_MAXQ = BWAHIP_MAX_READ_LEN;
 constexpr int CG_MAXT = 1536;                                // reference span of a region kept in LDS
-constexpr int CG_ZLDS = 12288;                               // backtrack matrix bytes kept in LDS
+constexpr int CG_ZLDS = 32768;                               // backtrack matrix bytes kept in LDS (reads of 192 bases and more; 8192 below)
 constexpr int CG_MAXC = 512;                                 // CIGAR operations staged in LDS
 constexpr int CG_MAXMD = 1024;                               // MD bytes staged in LDS
 constexpr unsigned long long CG_SLOT = 64;                   // bytes of pool every task owns (see reg2aln)
@@ -404,6 +404,59 @@ __device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen,
 	return __builtin_amdgcn_readlane(Hd, k_last);
 }
 
+// The same for bands of up to 128 diagonals (2w + 1 <= 128): lane k owns the two diagonals 2k and 2k + 1.  Even steps take the cell
+// of the even diagonal, odd steps the cell of the odd one -- both in row i = s/2 - k -- so every lane of the band works at every
+// step.  Inputs, all one step old: E of (i-1, 2k+1) and F of (i, 2k) are the lane's own; F of (i, 2k-1) comes from lane k - 1, E of
+// (i-1, 2k+2) from lane k + 1.
+__device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col)
+{
+	const int k = lane(), d0 = 2 * k, d1 = d0 + 1;
+	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
+	auto border = [&](int d) { return d >= w ? (d == w ? 0 : -(sw.o_ins + e_ins * (d - w))) : -(sw.o_del + e_del * (w - d)); };   // ksw.c:523-526 / 541
+	int H0 = border(d0), H1 = border(d1);
+	int E0 = NEG, F0 = NEG, E1 = NEG, F1 = NEG;
+	const int d_last = qlen - tlen + w;
+	const int steps = 2 * (tlen - 1) + d_last;
+	auto ldt = [&](int ii) { return (int)t[(ii < 0 ? 0 : ii < tlen ? ii : tlen - 1) * ts]; };
+	auto ldq = [&](int jj) { return (int)q[(jj < 0 ? 0 : jj < qlen ? jj : qlen - 1) * qs]; };
+	// scores one row ahead, bases two rows ahead (see wave_band_trace); row i of this lane's cells at iteration s is s/2 - k
+	int i = -k, j0 = -k - w + d0;                                // row / column of the even cell at s = 0 (negative: not yet in the matrix)
+	int tb1 = ldt(i), sc0 = sw.mat[tb1 * 5 + ldq(j0)], sc1 = sw.mat[tb1 * 5 + ldq(j0 + 1)];
+	int tn = ldt(i + 1), qa = ldq(j0 + 1), qb = ldq(j0 + 2);
+	auto cell = [&](int d, int ii, int jj, int sc, int ein, int fin, int &Hd, int &Eo, int &Fo) {
+		if (d <= 2 * w && ii >= 0 && ii < tlen && jj >= 0 && jj < qlen) {
+			int e = (ii >= 1 && d < 2 * w) ? ein : NEG;
+			int f = (jj >= 1 && d >= 1) ? fin : NEG;
+			const int m = Hd + sc;
+			int dd = m >= e ? 0 : 1;
+			int h = m >= e ? m : e;
+			dd = h >= f ? dd : 2;
+			h = h >= f ? h : f;
+			const int tD = m - oe_del;
+			e -= e_del;
+			dd |= e > tD ? 1 << 2 : 0;
+			Eo = e > tD ? e : tD;
+			const int tI = m - oe_ins;
+			f -= e_ins;
+			dd |= f > tI ? 2 << 4 : 0;
+			Fo = f > tI ? f : tI;
+			z[(size_t)ii * n_col + (ii > w ? d : jj)] = (uint8_t)dd;
+			Hd = h;
+		}
+	};
+	for (int s = 0; s <= steps; s += 2) {
+		const int c0 = sc0, c1 = sc1;
+		sc0 = sw.mat[tn * 5 + qa]; sc1 = sw.mat[tn * 5 + qb];
+		tn = ldt(i + 2); qa = ldq(j0 + 2); qb = ldq(j0 + 3);
+		const int Fl = __builtin_amdgcn_update_dpp(NEG, F1, 0x138, 0xf, 0xf, false);   // wave_shr:1  F of lane k - 1's odd diagonal
+		cell(d0, i, j0, c0, E1, Fl, H0, E0, F0);
+		const int Er = __builtin_amdgcn_update_dpp(NEG, E0, 0x130, 0xf, 0xf, false);   // wave_shl:1  E of lane k + 1's even diagonal (its cell of row i - 1 ... computed this step)
+		cell(d1, i, j0 + 1, c1, Er, F0, H1, E1, F1);
+		++i; ++j0;
+	}
+	return __builtin_amdgcn_readlane((d_last & 1) ? H1 : H0, d_last >> 1);
+}
+
 // decimal digits of a non-negative integer into dst; returns the count
 __device__ __forceinline__ int put_uint(uint8_t *dst, unsigned v)
 {
@@ -477,6 +530,7 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			// the fewest columns per lane that hold the query; CPLMAX (from the longest read of the batch) bounds what is
 			// compiled in, and with it the registers of the kernel
 			if (2 * w + 1 <= 64) score = wave_band_trace(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (2 * w + 1 <= 128) score = wave_band_trace2(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 2 || lq < 128) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 3 || lq < 192) score = wave_global_trace<(CPLMAX < 3 ? CPLMAX : 3)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
