@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""One-off large parity run on the GPU box: reads WITH indels, N's and chimeras (tools/simgen) against a repeat-rich genome,
+"""Manual (not collected by pytest) large parity run on the GPU box: reads WITH indels, N's and chimeras (tools/simgen) against a repeat-rich genome,
 single-end and paired-end, several read lengths / error rates; bwahip_process_seqs vs the CPU path (oracle/_ref/bwaref if present,
-else the C restatement), byte for byte.   python scripts/big_parity.py [genome_mbp] [reads]"""
+else the C restatement), byte for byte.   python tests/manual_big_parity.py [genome_mbp] [reads]"""
 import os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as entry
 bw = entry.load_bwahip(); bw.lib()
