@@ -186,7 +186,12 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 					if (f[k].qb < left_st) { left_st = f[k].qb; left_k = k; }
 				}
 				if (left_k != 0) {
-					const FinReg t = f[0]; f[0] = f[left_k]; f[left_k] = t;
+					{   // swap f[0] and f[left_k] 16 bytes at a time (a struct temporary would live in scratch memory)
+						uint4 *x = reinterpret_cast<uint4*>(f), *y = reinterpret_cast<uint4*>(f + left_k);
+						static_assert(sizeof(FinReg) == 96, "six 16-byte pieces");
+#pragma unroll
+						for (int q = 0; q < 6; ++q) { const uint4 tx = x[q], ty = y[q]; x[q] = ty; y[q] = tx; }
+					}
 					for (int k = 1; k < n; ++k) {
 						if (f[k].secondary == 0) f[k].secondary = left_k; else if (f[k].secondary == left_k) f[k].secondary = 0;
 						if (f[k].secondary_all == 0) f[k].secondary_all = left_k; else if (f[k].secondary_all == left_k) f[k].secondary_all = 0;

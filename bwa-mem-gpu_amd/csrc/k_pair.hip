@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64) void k_pair(PairLaunch a)
 		PKey *v = reinterpret_cast<PKey*>(scr[0]);                  // 16 B x (cap0 + cap1) >= nv entries (the two reads' scratch is contiguous)
 		auto make_key = [&](int t) {
 			const int r = t < n_pri[0] ? 0 : 1, i = r ? t - n_pri[0] : t;
-			const FinReg &e = f[r][i];
+			const FinReg &e = (r ? f[1] : f[0])[i];                  // (no dynamic index into the local pointer array: that would put it into scratch memory)
 			PKey k;
 			k.x = e.rb < l_pac ? (uint64_t)e.rb : (uint64_t)((l_pac << 1) - 1 - e.rb);
 			k.x = (uint64_t)e.rid << 32 | (k.x - (uint64_t)a.ix.anns[e.rid].offset);
@@ -508,56 +508,66 @@ __global__ __launch_bounds__(64) void k_pair(PairLaunch a)
 		wsync();
 		const int id = (int)((a.n_processed >> 1) + p);
 		// pass 1: the two largest elements of u (every admissible pair (k < i) with its score q and tie-breaking hash), and their number
-		PKey best = { 0, 0 }, second = { 0, 0 };
+		uint64_t bx = 0, by = 0, sx = 0, sy = 0;                    // best / second, field by field
 		int cnt = 0;
-		auto for_pairs = [&](auto &&fn) {
-			for (int i = l; i < nv; i += 64) {
-				const PKey vi = v[i];
-				for (int r = 0; r < 2; ++r) {
-					const int dir = r << 1 | (int)(vi.y >> 1 & 1);
-					if (a.pes[dir].failed) continue;
-					const int which = r << 1 | (int)((vi.y & 1) ^ 1);
-					for (int k = i - 1; k >= 0; --k) {
-						const PKey vk = v[k];
-						if ((int)(vk.y & 3) != which) continue;
-						const int64_t dist = (int64_t)vi.x - (int64_t)vk.x;
-						if (dist > a.pes[dir].high) break;
-						if (dist < a.pes[dir].low) continue;
-						int q = (int)((double)((vi.y >> 32) + (vk.y >> 32)) + a.pair_tab[a.tab_off[dir] + (int)(dist - a.pes[dir].low)] * opt.a + .499);
-						if (q < 0) q = 0;
-						PKey u;
-						u.y = (uint64_t)k << 32 | (uint64_t)i;
-						u.x = (uint64_t)q << 32 | (hash_64(u.y ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU);
-						fn(u);
-					}
-				}
-			}
-		};
-		for_pairs([&](const PKey &u) {
+		// every admissible pair (k < i) of the sorted list (bwamem_pair.c:232-246) as (ux, uy) = (score << 32 | hash, k << 32 | i).  A macro, not a
+		// lambda: what a lambda's callers capture by reference ends up in scratch memory unless everything is inlined
+#define FOR_PAIRS(BODY) \
+		for (int i = l; i < nv; i += 64) { \
+			const PKey vi = v[i]; \
+			for (int r = 0; r < 2; ++r) { \
+				const int dir = r << 1 | (int)(vi.y >> 1 & 1); \
+				if (a.pes[dir].failed) continue; \
+				const int which = r << 1 | (int)((vi.y & 1) ^ 1); \
+				for (int k = i - 1; k >= 0; --k) { \
+					const PKey vk = v[k]; \
+					if ((int)(vk.y & 3) != which) continue; \
+					const int64_t dist = (int64_t)vi.x - (int64_t)vk.x; \
+					if (dist > a.pes[dir].high) break; \
+					if (dist < a.pes[dir].low) continue; \
+					int q = (int)((double)((vi.y >> 32) + (vk.y >> 32)) + a.pair_tab[a.tab_off[dir] + (int)(dist - a.pes[dir].low)] * opt.a + .499); \
+					if (q < 0) q = 0; \
+					const uint64_t uy = (uint64_t)k << 32 | (uint64_t)i; \
+					const uint64_t ux = (uint64_t)q << 32 | (hash_64(uy ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU); \
+					BODY \
+				} \
+			} \
+		}
+		FOR_PAIRS({
 			++cnt;
-			if (cnt == 1 || pk_lt(best, u)) { if (cnt > 1) second = best; best = u; }
-			else if (cnt == 2 || pk_lt(second, u)) second = u;
-		});
+			// value selects only: "if (c) a = u; else b = u;" is turned into a store through a selected ADDRESS, which pins a and b in scratch
+			const bool top1 = cnt == 1 || bx < ux || (bx == ux && by < uy);
+			const bool top2 = !top1 && (cnt == 2 || sx < ux || (sx == ux && sy < uy));
+			const uint64_t nsx = top1 ? (cnt > 1 ? bx : sx) : top2 ? ux : sx; const uint64_t nsy = top1 ? (cnt > 1 ? by : sy) : top2 ? uy : sy;
+			bx = top1 ? ux : bx; by = top1 ? uy : by; sx = nsx; sy = nsy;
+		})
+
 		// (best, second) per lane -> of the wavefront.  A lane with no pair offers {0,0}; real elements have y >= 1 (i >= 1)
 		const int n_u = wsum(cnt);
 		if (n_u > 0) {
 			const int my_cnt = cnt;
-			PKey mine = my_cnt ? best : PKey{ 0, 0 };
+			// (selected field by field: a conditional between whole structs is compiled as a choice between their addresses, which
+			// pins them in scratch memory)
+			PKey mine;
+			mine.x = my_cnt ? bx : 0; mine.y = my_cnt ? by : 0;
 			const PKey top = wmax_pk(mine);
 			const bool holder = my_cnt && mine.x == top.x && mine.y == top.y;
-			PKey off2 = holder ? (my_cnt > 1 ? second : PKey{ 0, 0 }) : mine;
+			PKey off2;
+			off2.x = holder ? (my_cnt > 1 ? sx : 0) : mine.x; off2.y = holder ? (my_cnt > 1 ? sy : 0) : mine.y;
 			const PKey sec = wmax_pk(off2);
 			int tmp = opt.a + opt.b;
 			tmp = tmp > opt.o_del + opt.e_del ? tmp : opt.o_del + opt.e_del;
 			tmp = tmp > opt.o_ins + opt.e_ins ? tmp : opt.o_ins + opt.e_ins;
 			const int ti = (int)(top.y & 0xffffffffu), tk = (int)(top.y >> 32);
-			z[v[ti].y & 1] = (int)((v[ti].y & 0xffffffffu) >> 2);
-			z[v[tk].y & 1] = (int)((v[tk].y & 0xffffffffu) >> 2);
+			{ const PKey a_ = v[ti], b_ = v[tk]; const int za = (int)((a_.y & 0xffffffffu) >> 2), zb = (int)((b_.y & 0xffffffffu) >> 2);
+			  if (a_.y & 1) z[1] = za; else z[0] = za;
+			  if (b_.y & 1) z[1] = zb; else z[0] = zb; }
 			const int o = (int)(top.x >> 32);
 			int subo = n_u > 1 ? (int)(sec.x >> 32) : 0, n_sub = 0;
 			{   // pass 2: bwamem_pair.c:266-268 -- all but the top element whose score is within tmp of subo
 				int c2 = 0;
-				for_pairs([&](const PKey &u) { if (subo - (int)(u.x >> 32) <= tmp) ++c2; });
+				FOR_PAIRS({ (void)uy; if (subo - (int)(ux >> 32) <= tmp) ++c2; })
+#undef FOR_PAIRS
 				n_sub = wsum(c2) - 1;
 			}
 			if (o > 0) {
