@@ -99,9 +99,16 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 	const DevOpt &opt = a.opt;
 	const int n = a.reg_n[r];
 	const int64_t rb0 = a.reg_base[r];
-	FinReg *f = a.fregs + rb0, *g = a.fregs2 + rb0;
-	int *z = a.scr + 4 * rb0;                                   // n ints; the next 3n ints: sort keys (16 B each would need 4n: keys live in g's slots' tail instead)
-	SortKey *keys = reinterpret_cast<SortKey*>(a.scr + 4 * rb0);   // 16 B per region = the whole 4-int scratch; z is taken after the sorts
+	// Reads with up to MK_LDS regions (all but a few) are marked in LDS and written to HBM once at the end: the work is a chain of small
+	// dependent steps (sort, pairwise overlap tests, index fix-ups), each a memory round trip -- in HBM that chain is what the kernel waits for
+	constexpr int MK_LDS = 32;
+	__shared__ __attribute__((aligned(16))) FinReg s_f[MK_LDS], s_g[MK_LDS];
+	__shared__ __attribute__((aligned(16))) SortKey s_keys[MK_LDS];
+	__shared__ int s_z[2 * MK_LDS];
+	const bool in_lds = n <= MK_LDS;
+	FinReg *f = in_lds ? s_f : a.fregs + rb0, *g = in_lds ? s_g : a.fregs2 + rb0;
+	int *z = in_lds ? s_z : a.scr + 4 * rb0;                    // n ints (2n for select_records); in HBM they share the 4-int scratch of a region slot with the sort keys
+	SortKey *keys = in_lds ? s_keys : reinterpret_cast<SortKey*>(a.scr + 4 * rb0);   // 16 B per region; z is taken after the sorts
 	if (l == 0) { a.freg_n[r] = n; }
 	if (n == 0) { if (l == 0) { a.n_pri[r] = 0; if (PLAN) { a.task_n[r] = 0; a.rec_n[r] = 0; } } return; }
 	// id of region i for the tie-breaking hash (bwamem.c:534): SE n_processed + read; PE ((n_processed>>1) + pair)<<1 | end
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 			q.qb = p.qb; q.qe = p.qe; q.rid = p.rid; q.score = p.score; q.truesc = p.truesc; q.sub = 0; q.alt_sc = 0; q.csub = p.csub;
 			q.sub_n = p.sub_n; q.w = p.w; q.seedcov = p.seedcov; q.secondary = -1; q.secondary_all = -1; q.seedlen0 = p.seedlen0;
 			q.n_comp = p.n_comp; q.is_alt = p.is_alt; q.pad = 0;
-			f[0] = q;
+			a.fregs[rb0] = q;
 			a.n_pri[r] = p.is_alt ? 0 : 1;
 			if (PLAN) {
 				const int rec = q.score >= opt.T ? 1 : 0;
@@ -201,11 +208,17 @@ __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 		}
 		wsync();
 	}
-	if (!PLAN) return;
-
-	int n_task, n_rec;
-	select_records(opt, n, f, a.need + rb0, a.xa_owner + rb0, z, l, n_task, n_rec);
-	if (l == 0) { a.task_n[r] = n_task; a.rec_n[r] = n_rec; }
+	if (PLAN) {
+		int n_task, n_rec;
+		select_records(opt, n, f, a.need + rb0, a.xa_owner + rb0, z, l, n_task, n_rec);
+		if (l == 0) { a.task_n[r] = n_task; a.rec_n[r] = n_rec; }
+	}
+	if (in_lds) {                                               // the marked regions to HBM, 16 bytes per lane and step
+		wsync();
+		const uint4 *src = reinterpret_cast<const uint4*>(s_f);
+		uint4 *dst = reinterpret_cast<uint4*>(a.fregs + rb0);
+		for (int i = l; i < n * 6; i += 64) dst[i] = src[i];
+	}
 }
 
 __device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q, int r)   // bwamem.c:799
