@@ -33,61 +33,91 @@ template <int MODE> __device__ __forceinline__ bool key_lt(const SortKey &a, con
 	return a.is_alt < b.is_alt || (a.is_alt == b.is_alt && (a.score > b.score || (a.score == b.score && a.hash < b.hash)));
 }
 
-// mem_mark_primary_se_core (bwamem.c:500-526) on f[0..n): z = list of kept (non-secondary) regions.  Region i is tested
-// against the kept ones, one per lane; the reference stops at the FIRST kept region it overlaps significantly.
+// mem_mark_primary_se_core (bwamem.c:500-526) on f[0..n).  The reference takes the regions in order and tests each against the kept
+// (non-secondary) ones before it, stopping at the FIRST it overlaps significantly.  Turned around here: the next kept region j is the
+// first one not marked yet; every later unmarked region is tested against j at once, one per lane.  A region still ends up as the
+// secondary of the first kept region it overlaps, kept regions are the same set, and j's sub (the score of the first region it
+// absorbed) and sub_n (how many of them count, bwamem.c:517-518) do not depend on the order -- but the number of dependent steps is
+// the number of KEPT regions (a handful) instead of the number of regions (hundreds for a read inside a repeat family).
 __device__ void mark_core(const DevOpt &opt, int n, FinReg *f, int *z, int l)
 {
 	int tmp = opt.a + opt.b;
 	tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
 	tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
 	if (n <= 0) return;
-	if (l == 0) z[0] = 0;
-	int nz = 1;
-	wsync();
-	for (int i = 1; i < n; ++i) {
-		const int iqb = f[i].qb, iqe = f[i].qe, isc = f[i].score, ialt = f[i].is_alt;
-		int hit = -1;
-		for (int base = 0; base < nz && hit < 0; base += 64) {
-			const int k = base + l;
-			bool sig = false;
-			if (k < nz) {
-				const int j = z[k];
-				const int jqb = f[j].qb, jqe = f[j].qe;
+	(void)z;
+	int j = 0;                                                  // region 0 is kept (bwamem.c:506)
+	while (j >= 0) {
+		const int jqb = f[j].qb, jqe = f[j].qe, jsc = f[j].score, jalt = f[j].is_alt;
+		int first_i = 0x7fffffff, n_cnt = 0, next = 0x7fffffff;
+		for (int base = j + 1; base < n; base += 64) {
+			const int i = base + l;
+			bool sig = false, counts = false, open = false;
+			if (i < n && f[i].secondary < 0) {
+				const int iqb = f[i].qb, iqe = f[i].qe;
 				const int b_max = jqb > iqb ? jqb : iqb, e_min = jqe < iqe ? jqe : iqe;
 				if (e_min > b_max) {
 					const int min_l = iqe - iqb < jqe - jqb ? iqe - iqb : jqe - jqb;
 					if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level) sig = true;
 				}
+				if (sig) { f[i].secondary = j; counts = jsc - f[i].score <= tmp && (jalt || !f[i].is_alt); }
+				else open = true;
 			}
-			const unsigned long long m = __ballot(sig);
-			if (m) hit = base + __ffsll((long long)m) - 1;
-		}
-		if (hit >= 0) {
-			if (l == 0) {
-				const int j = z[hit];
-				if (f[j].sub == 0) f[j].sub = isc;
-				if (f[j].score - isc <= tmp && (f[j].is_alt || !ialt)) ++f[j].sub_n;
-				f[i].secondary = j;
-			}
-		} else {
-			if (l == 0) z[nz] = i;
-			++nz;
+			const unsigned long long ms = __ballot(sig), mo = __ballot(open);
+			if (ms && first_i == 0x7fffffff) first_i = base + __ffsll((long long)ms) - 1;
+			n_cnt += __popcll(__ballot(counts));
+			if (mo && next == 0x7fffffff) next = base + __ffsll((long long)mo) - 1;
 		}
 		wsync();
+		if (first_i != 0x7fffffff && l == 0) {
+			if (f[j].sub == 0) f[j].sub = f[first_i].score;
+			f[j].sub_n += n_cnt;
+		}
+		wsync();
+		j = next == 0x7fffffff ? -1 : next;                       // the first region left unmarked is kept too (nothing kept before it overlaps it)
 	}
 }
 
-// rank sort of f[0..n) into g[0..n) by MODE's order (keys unique); keys in `keys`
+// Sort f[0..n) into g[0..n) by MODE's order; the keys (unique) go to `keys`.  Up to 128 regions: rank sort, every lane counts the keys
+// below its own (n^2 / 64 comparisons per lane).  Longer lists -- a read inside a repeat family has hundreds of regions, and its sort
+// would set the duration of the whole kernel -- take a bitonic network over an index array (kept in g's memory, which is only written
+// at the very end): log^2 steps of n / 128 compare-exchanges per lane.
 template <int MODE> __device__ void rank_sort(int n, const FinReg *f, FinReg *g, SortKey *keys, int l)
 {
 	for (int i = l; i < n; i += 64) { keys[i].score = f[i].score; keys[i].is_alt = f[i].is_alt; keys[i].hash = f[i].hash; }
 	wsync();
-	for (int i = l; i < n; i += 64) {
-		const SortKey ki = keys[i];
-		int rank = 0;
-		for (int j = 0; j < n; ++j) rank += key_lt<MODE>(keys[j], ki) ? 1 : 0;
-		g[rank] = f[i];
+	if (n <= 128) {
+		for (int i = l; i < n; i += 64) {
+			const SortKey ki = keys[i];
+			int rank = 0;
+			for (int j = 0; j < n; ++j) rank += key_lt<MODE>(keys[j], ki) ? 1 : 0;
+			g[rank] = f[i];
+		}
+		wsync();
+		return;
 	}
+	int m = 256;
+	while (m < n) m <<= 1;
+	int *perm = reinterpret_cast<int*>(g);                      // m <= 2n ints fit in n regions of 96 bytes
+	for (int p = l; p < m; p += 64) perm[p] = p < n ? p : -1;    // -1: padding, sorts behind everything
+	wsync();
+	auto before = [&](int x, int y) { return x >= 0 && (y < 0 || key_lt<MODE>(keys[x], keys[y])); };
+	for (int k = 2; k <= m; k <<= 1) {
+		for (int j = k >> 1, lj = 31 - __clz(k >> 1); j > 0; j >>= 1, --lj) {
+			for (int t = l; t < (m >> 1); t += 64) {
+				const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), q = i + j;
+				const int x = perm[i], y = perm[q];
+				const bool up = (i & k) == 0;
+				if (up ? before(y, x) : before(x, y)) { perm[i] = y; perm[q] = x; }
+			}
+			wsync();
+		}
+	}
+	// the order into the (now free) key array, then the regions to their places -- g is overwritten from here on
+	int *order = reinterpret_cast<int*>(keys);
+	for (int p = l; p < n; p += 64) order[p] = perm[p];
+	wsync();
+	for (int p = l; p < n; p += 64) g[p] = f[order[p]];
 	wsync();
 }
 
