@@ -272,6 +272,7 @@ struct PairLaunch {
 	// pairing
 	const FinReg *fregs; const int *freg_n; const int *n_pri;   // after k_mark on the pe lists (fregs is written: sub / secondary updates of bwamem_pair.c:347-350, 359-365)
 	FinReg *fregs_w;
+	FinReg *fregs_tmp;                                         // k_mark's second region array: free by the time k_pair runs (sort space of heavy pairs)
 	uint8_t *need; int *xa_owner; int *task_n, *rec_n; int *scr;
 	PeRead *pe_read;
 	int *err;

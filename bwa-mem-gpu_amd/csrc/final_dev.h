@@ -50,12 +50,26 @@ __device__ void select_records(const DevOpt &opt, int n, const FinReg *f, uint8_
 	wsync();
 	const bool want_xa = !(opt.flag & BWAHIP_F_ALL);
 	if (want_xa) {
-		for (int i = l; i < n; i += 64) {
-			const int k = f[i].secondary_all;
-			int pr = -1;
-			if (k >= 0 && (double)f[i].score >= (double)f[k].score * (double)opt.XA_drop_ratio) pr = k;   // get_pri_idx: int >= int * double
-			owner[i] = pr;
-			if (pr >= 0) { atomicAdd(&cnt[pr], 1); if (f[i].is_alt) atomicOr(&has_alt[pr], 1); }
+		for (int base = 0; base < n; base += 64) {
+			const int i = base + l;
+			int pr = -1, alt = 0;
+			if (i < n) {
+				const int k = f[i].secondary_all;
+				if (k >= 0 && (double)f[i].score >= (double)f[k].score * (double)opt.XA_drop_ratio) pr = k;   // get_pri_idx: int >= int * double
+				owner[i] = pr;
+				alt = f[i].is_alt;
+			}
+			// counts per primary, one update per distinct primary among the 64 lanes (a read inside a repeat family has hundreds of hits
+			// under ONE primary: an atomic per hit would queue them all on one address)
+			unsigned long long todo = __ballot(pr >= 0);
+			while (todo) {
+				const int lead = __ffsll((long long)todo) - 1;
+				const int p0 = __shfl(pr, lead);
+				const unsigned long long same = __ballot(pr == p0);
+				const unsigned long long any_alt = __ballot(pr == p0 && alt);
+				if (l == lead) { cnt[p0] += __popcll(same); if (any_alt) has_alt[p0] = 1; }
+				todo &= ~same;
+			}
 		}
 		wsync();
 	}

@@ -197,7 +197,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	if ((rc = launch_mark_primary(f, !pe, c->stream))) return rc;
 	if (pe) {                                                     // mem_pair + the decisions of mem_sam_pe
 		if ((rc = c->d_pe_read.ensure((size_t)n * sizeof(PeRead)))) return rc;
-		pl.fregs = f.fregs; pl.fregs_w = f.fregs; pl.freg_n = f.freg_n; pl.n_pri = f.n_pri; pl.need = f.need; pl.xa_owner = f.xa_owner;
+		pl.fregs = f.fregs; pl.fregs_w = f.fregs; pl.fregs_tmp = f.fregs2; pl.freg_n = f.freg_n; pl.n_pri = f.n_pri; pl.need = f.need; pl.xa_owner = f.xa_owner;
 		pl.task_n = f.task_n; pl.rec_n = f.rec_n; pl.scr = f.scr; pl.pe_read = c->d_pe_read.as<PeRead>();
 		if ((rc = launch_pair(pl, c->stream))) return rc;
 		f.pe_read = pl.pe_read;

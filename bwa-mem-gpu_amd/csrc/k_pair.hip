@@ -499,11 +499,35 @@ __global__ __launch_bounds__(64) void k_pair(PairLaunch a)
 			k.y = (uint64_t)e.score << 32 | (uint64_t)(i << 2) | (uint64_t)((e.rb >= l_pac) << 1) | (uint64_t)r;
 			return k;
 		};
-		for (int t = l; t < nv; t += 64) {
-			const PKey kt = make_key(t);
+		if (nv <= 64) {                                             // one key per lane; the others come by shuffle (rank sort: the keys are unique)
+			PKey kt = { ~0ull, ~0ull };
+			if (l < nv) kt = make_key(l);
 			int rank = 0;
-			for (int u = 0; u < nv; ++u) rank += pk_lt(make_key(u), kt) ? 1 : 0;
-			v[rank] = kt;
+			for (int u = 0; u < nv; ++u) {
+				PKey ku;
+				ku.x = (uint64_t)__shfl((long long)kt.x, u); ku.y = (uint64_t)__shfl((long long)kt.y, u);
+				rank += pk_lt(ku, kt) ? 1 : 0;
+			}
+			if (l < nv) v[rank] = kt;
+		} else {
+			// a pair inside a repeat family (hundreds of regions per end; its sort would set the duration of the whole kernel): the keys are
+			// written once and ordered by a bitonic network in the second region array, which nothing uses any more
+			int m = 128;
+			while (m < nv) m <<= 1;
+			PKey *w = reinterpret_cast<PKey*>(a.fregs_tmp + a.pe_base[r0]);      // 96 B x (regions of both ends) >= 16 B x 2 nv >= 16 B x m
+			for (int t = l; t < m; t += 64) w[t] = t < nv ? make_key(t) : PKey{ ~0ull, ~0ull };
+			wsync();
+			for (int k = 2; k <= m; k <<= 1) {
+				for (int j = k >> 1, lj = 31 - __clz(k >> 1); j > 0; j >>= 1, --lj) {
+					for (int t = l; t < (m >> 1); t += 64) {
+						const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), q = i + j;
+						const PKey x = w[i], y = w[q];
+						if (((i & k) == 0) ? pk_lt(y, x) : pk_lt(x, y)) { w[i] = y; w[q] = x; }
+					}
+					wsync();
+				}
+			}
+			for (int t = l; t < nv; t += 64) v[t] = w[t];
 		}
 		wsync();
 		const int id = (int)((a.n_processed >> 1) + p);
@@ -573,10 +597,13 @@ __global__ __launch_bounds__(64) void k_pair(PairLaunch a)
 			if (o > 0) {
 				// ---- bwamem_pair.c:312-365
 				int is_multi[2];
-				for (int i = 0; i < 2; ++i) {
-					int j;
-					for (j = 1; j < n_pri[i]; ++j) if (f[i][j].secondary < 0 && f[i][j].score >= opt.T) break;
-					is_multi[i] = j < n_pri[i] ? 1 : 0;
+				for (int i = 0; i < 2; ++i) {                         // bwamem_pair.c:314-317: any further primary hit above T?  64 regions per step
+					is_multi[i] = 0;
+					for (int base = 1; base < n_pri[i] && !is_multi[i]; base += 64) {
+						const int j = base + l;
+						const bool hit = j < n_pri[i] && f[i][j].secondary < 0 && f[i][j].score >= opt.T;
+						if (__ballot(hit)) is_multi[i] = 1;
+					}
 				}
 				if (!(is_multi[0] || is_multi[1])) {
 					paired = true;
