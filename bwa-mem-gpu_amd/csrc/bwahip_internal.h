@@ -211,6 +211,9 @@ struct FinLaunch {
 	const DevReg *regs; const int64_t *reg_base; const int *reg_n;
 	// mark primary: fregs at the same slots, in the reference's final order; n_pri per read; scratch
 	FinReg *fregs, *fregs2; int *freg_n, *n_pri; int *scr;     // scr: 4 ints per region slot
+	// paired end: the pairs mate rescue works on are finalised in a second launch, after their rescue (which runs beside the first launch).
+	// subset 0: all reads; 1: all but the pairs flagged in resc_flag; 2: the pairs of resc_list only (grid = 2 x their number)
+	const uint8_t *resc_flag; const int *resc_pairs; int subset;
 	uint8_t *need; int *xa_owner;                // per region slot
 	int *task_n, *rec_n;                         // per read: regions needing reg2aln; SAM records
 	// alignment tasks
@@ -231,7 +234,7 @@ struct FinLaunch {
 	const PeRead *pe_read; DevPes pes[4];        // paired-end batches: per-read decisions of k_pair, insert-size statistics
 	int *err;
 };
-int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st);
+int launch_mark_primary(const FinLaunch &a, bool plan, int n_listed, hipStream_t st);   // subset 2: n_listed pairs of resc_pairs
 int launch_task_fill(const FinLaunch &a, hipStream_t st);
 int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st);   // the tasks k_cigar listed in redo_list; big_z: grid slabs of cigar_big_slab_bytes()
@@ -272,6 +275,7 @@ struct PairLaunch {
 	// pairing
 	const FinReg *fregs; const int *freg_n; const int *n_pri;   // after k_mark on the pe lists (fregs is written: sub / secondary updates of bwamem_pair.c:347-350, 359-365)
 	FinReg *fregs_w;
+	uint8_t *resc_flag; int subset;                           // see FinLaunch
 	FinReg *fregs_tmp;                                         // k_mark's second region array: free by the time k_pair runs (sort space of heavy pairs)
 	uint8_t *need; int *xa_owner; int *task_n, *rec_n; int *scr;
 	PeRead *pe_read;
@@ -282,7 +286,7 @@ int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
 int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
 int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st);
-int launch_pair(const PairLaunch &a, hipStream_t st);
+int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st);   // subset 2: n_listed pairs of resc_list
 size_t matesw_slab_bytes(int64_t window);
 int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st);
 

@@ -108,6 +108,7 @@ struct bwahip_ctx {
 	bwahip_pestat_t last_pes[4];         // insert-size statistics of the last paired-end batch
 	unsigned long long last_pe_counters[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // mate-rescue alignments run / regions added / most per pair / pairs rescued
 	DevBuf d_task_lists;                 // k_cigar's two work lists (no-DP tasks, DP tasks)
+	DevBuf d_resc_flag;                  // one byte per pair: mate rescue works on it (finalised by the second k_mark / k_pair launch)
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
 	HostBuf h_stage, h_sam;               // pinned staging: batch text in, SAM text out
 	int64_t total_tasks = 0, total_sam = 0;

@@ -67,7 +67,9 @@ static void pestat_from_hist(const bwahip_opt_t *opt, const std::vector<unsigned
 }
 
 // The paired-end stages before mark-primary: insert-size statistics, mate rescue.  Leaves the per-read lists in d_pe_regs.
-static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &dopt, int64_t n_processed, const bwahip_pestat_t *pes0, PairLaunch &pl)
+// Insert sizes, the lists of both ends, and mate rescue.  The rescue kernels (a handful of pairs, long dependent chains: the GPU is nearly idle
+// under them) go to the second stream and are NOT waited for: run_final finalises all other pairs meanwhile and the rescued ones after ev_join.
+static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &dopt, int64_t n_processed, const bwahip_pestat_t *pes0, PairLaunch &pl, int &n_resc_out)
 {
 	const int n = c->n_reads;
 	int rc;
@@ -111,9 +113,10 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	pl.pair_tab = c->d_pair_tab.as<double>();
 	// list capacities after rescue
 	if ((rc = c->d_nb.ensure((size_t)n * 4)) || (rc = c->d_pe_cap.ensure((size_t)n * 4)) || (rc = c->d_pe_base.ensure((size_t)(n + 1) * 8)) || (rc = c->d_pe_n.ensure((size_t)n * 4)) ||
-	    (rc = c->d_resc.ensure((size_t)(n / 2 + 4) * 4)) || (rc = c->d_sw_cnt.ensure((size_t)n * 4)) || (rc = c->d_sw_base.ensure((size_t)(n + 1) * 8))) return rc;
+	    (rc = c->d_resc.ensure((size_t)(n / 2 + 4) * 4)) || (rc = c->d_resc_flag.ensure((size_t)(n / 2 + 4))) || (rc = c->d_sw_cnt.ensure((size_t)n * 4)) || (rc = c->d_sw_base.ensure((size_t)(n + 1) * 8))) return rc;
 	pl.sw_cnt = c->d_sw_cnt.as<int>(); pl.sw_base = c->d_sw_base.as<int64_t>();
-	pl.nb = c->d_nb.as<int>(); pl.pe_cap = c->d_pe_cap.as<int>(); pl.pe_base = c->d_pe_base.as<int64_t>(); pl.pe_n = c->d_pe_n.as<int>(); pl.resc_list = c->d_resc.as<int>();
+	pl.nb = c->d_nb.as<int>(); pl.pe_cap = c->d_pe_cap.as<int>(); pl.pe_base = c->d_pe_base.as<int64_t>(); pl.pe_n = c->d_pe_n.as<int>(); pl.resc_list = c->d_resc.as<int>(); pl.resc_flag = c->d_resc_flag.as<uint8_t>();
+	HIP_TRY(hipMemsetAsync(c->d_resc_flag.p, 0, (size_t)(n / 2 + 4), c->stream));
 	if ((rc = launch_pe_prepare(pl, c->stream))) return rc;
 	if ((rc = launch_scan(pl.pe_cap, c->d_pe_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
 	if ((rc = launch_scan(pl.sw_cnt, c->d_sw_base.as<int64_t>(), n, c->d_scan, c->stream))) return rc;
@@ -136,18 +139,21 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	HIP_TRY(hipMemcpyAsync(&n_resc, pl.resc_n, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&n_sw_tasks, pl.sw_n, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->stream))) return rc;   // the alignments against the unrescued lists, all at once
-	if (n_resc > 0) {
-		const int grid = std::min(n_resc, 2048);
-		pl.slab_stride = (matesw_slab_bytes(widest + c->max_len) + 255) & ~(size_t)255;
-		if ((rc = c->d_ms_slab.ensure(pl.slab_stride * (size_t)grid))) return rc;
-		pl.slab = c->d_ms_slab.as<uint8_t>();
-		if ((rc = launch_matesw(pl, grid, c->stream))) return rc;
-	}
-	HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 72, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	n_resc_out = n_resc;
 	c->last_pe_counters[3] = (unsigned long long)n_resc;
-	if (c->knobs.verbose) fprintf(stderr, "[bwahip] mate rescue: %llu SW, %llu added, max %llu per pair, %d pairs, %llu aligned inside the sequential pass; ticks(10ns) window %llu sw %llu dedup %llu, slowest pair %llu\n", c->last_pe_counters[0], c->last_pe_counters[1], c->last_pe_counters[2], n_resc, c->last_pe_counters[8], c->last_pe_counters[4], c->last_pe_counters[5], c->last_pe_counters[6], c->last_pe_counters[7]);
+	if (n_resc > 0 || n_sw_tasks > 0) {
+		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+		if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->stream2))) return rc;   // the alignments against the unrescued lists, all at once
+		if (n_resc > 0) {
+			const int grid = std::min(n_resc, 2048);
+			pl.slab_stride = (matesw_slab_bytes(widest + c->max_len) + 255) & ~(size_t)255;
+			if ((rc = c->d_ms_slab.ensure(pl.slab_stride * (size_t)grid))) return rc;
+			pl.slab = c->d_ms_slab.as<uint8_t>();
+			if ((rc = launch_matesw(pl, grid, c->stream2))) return rc;
+		}
+		HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+	}
 	return 0;
 }
 
@@ -164,7 +170,8 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	if (timed) HIP_TRY(hipEventRecord(c->ev[20], c->stream));
 	PairLaunch pl;
 	const DevOpt dopt_pe = make_dev_opt(opt);
-	if (pe && (rc = run_pe_rescue(c, opt, dopt_pe, n_processed, pes0, pl))) return rc;
+	int n_resc = 0;
+	if (pe && (rc = run_pe_rescue(c, opt, dopt_pe, n_processed, pes0, pl, n_resc))) return rc;
 	const size_t R = (size_t)(c->total_regs ? c->total_regs : 1);
 	if ((rc = c->d_fregs.ensure(R * sizeof(FinReg))) || (rc = c->d_fregs2.ensure(R * sizeof(FinReg))) || (rc = c->d_fscr.ensure(R * 16)) || (rc = c->d_need.ensure(R)) ||
 	    (rc = c->d_xa_owner.ensure(R * 4)) || (rc = c->d_aln_of_reg.ensure(R * 4)) || (rc = c->d_rec_list.ensure(R * 8)) || (rc = c->d_xa_list.ensure(R * 8)) ||
@@ -194,12 +201,23 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	f.rg_id = c->d_rg.as<uint8_t>(); f.rg_len = (int)c->rg_id.size();
 	f.sam_len = c->d_sam_len.as<int>(); f.sam_off = c->d_sam_off.as<int64_t>();
 	if (timed) HIP_TRY(hipEventRecord(c->ev[15], c->stream));
-	if ((rc = launch_mark_primary(f, !pe, c->stream))) return rc;
+	// paired end: first every pair mate rescue does not touch, while the rescue kernels run on the second stream; then, once those are done, their pairs
+	if (pe) { f.resc_flag = pl.resc_flag; f.resc_pairs = pl.resc_list; f.subset = 1; }
+	if ((rc = launch_mark_primary(f, !pe, 0, c->stream))) return rc;
 	if (pe) {                                                     // mem_pair + the decisions of mem_sam_pe
 		if ((rc = c->d_pe_read.ensure((size_t)n * sizeof(PeRead)))) return rc;
 		pl.fregs = f.fregs; pl.fregs_w = f.fregs; pl.fregs_tmp = f.fregs2; pl.freg_n = f.freg_n; pl.n_pri = f.n_pri; pl.need = f.need; pl.xa_owner = f.xa_owner;
 		pl.task_n = f.task_n; pl.rec_n = f.rec_n; pl.scr = f.scr; pl.pe_read = c->d_pe_read.as<PeRead>();
-		if ((rc = launch_pair(pl, c->stream))) return rc;
+		pl.subset = 1;
+		if ((rc = launch_pair(pl, 0, c->stream))) return rc;
+		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));      // the rescue kernels (an event not recorded in this batch is complete: no wait)
+		if (n_resc > 0) {
+			f.subset = 2; pl.subset = 2;
+			if ((rc = launch_mark_primary(f, false, n_resc, c->stream))) return rc;
+			if ((rc = launch_pair(pl, n_resc, c->stream))) return rc;
+		}
+		f.subset = 0; pl.subset = 0;
+		HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 24, hipMemcpyDeviceToHost, c->stream));   // [0..2]; [3] = pairs rescued is the host's
 		f.pe_read = pl.pe_read;
 		memcpy(f.pes, pl.pes, sizeof f.pes);
 	}

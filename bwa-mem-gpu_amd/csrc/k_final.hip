@@ -125,7 +125,9 @@ template <int MODE> __device__ void rank_sort(int n, const FinReg *f, FinReg *g,
 template <bool PLAN>
 __global__ __launch_bounds__(64) void k_mark(FinLaunch a)
 {
-	const int r = blockIdx.x, l = lane();
+	const int l = lane();
+	const int r = a.subset == 2 ? (a.resc_pairs[blockIdx.x >> 1] << 1 | (int)(blockIdx.x & 1)) : (int)blockIdx.x;
+	if (a.subset == 1 && a.resc_flag[r >> 1]) return;           // finalised after its rescue, by the second launch
 	const DevOpt &opt = a.opt;
 	const int n = a.reg_n[r];
 	const int64_t rb0 = a.reg_base[r];
@@ -765,11 +767,12 @@ __global__ __launch_bounds__(64) void k_cigar_big(FinLaunch a)
 
 } // namespace
 
-int launch_mark_primary(const FinLaunch &a, bool plan, hipStream_t st)
+int launch_mark_primary(const FinLaunch &a, bool plan, int n_listed, hipStream_t st)
 {
-	if (a.n_reads <= 0) return 0;
-	if (plan) hipLaunchKernelGGL(k_mark<true>, dim3(a.n_reads), dim3(64), 0, st, a);
-	else hipLaunchKernelGGL(k_mark<false>, dim3(a.n_reads), dim3(64), 0, st, a);
+	const int grid = a.subset == 2 ? 2 * n_listed : a.n_reads;
+	if (grid <= 0) return 0;
+	if (plan) hipLaunchKernelGGL(k_mark<true>, dim3(grid), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_mark<false>, dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 

@@ -166,7 +166,7 @@ __global__ void k_pe_copy(PairLaunch a)
 				}
 		}
 	}
-	if (need) a.resc_list[atomicAdd(a.resc_n, 1)] = p;
+	if (need) { a.resc_list[atomicAdd(a.resc_n, 1)] = p; a.resc_flag[p] = 1; }
 }
 
 // ---------------------------------------------------------------------------------------------------- mem_matesw
@@ -472,7 +472,9 @@ __device__ __forceinline__ PKey wmax_pk(PKey v)
 // One pair per wavefront.
 __global__ __launch_bounds__(64) void k_pair(PairLaunch a)
 {
-	const int p = blockIdx.x, l = lane();
+	const int l = lane();
+	const int p = a.subset == 2 ? a.resc_list[blockIdx.x] : (int)blockIdx.x;
+	if (a.subset == 1 && a.resc_flag[p]) return;                 // finalised after its rescue, by the second launch
 	const DevOpt &opt = a.opt;
 	const int64_t l_pac = a.ix.l_pac;
 	const int r0 = p << 1;
@@ -745,9 +747,9 @@ int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st)
 	hipLaunchKernelGGL(k_matesw_sw, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
-int launch_pair(const PairLaunch &a, hipStream_t st)
+int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st)
 {
-	const int np = a.n_reads >> 1;
+	const int np = a.subset == 2 ? n_listed : a.n_reads >> 1;
 	if (np <= 0) return 0;
 	hipLaunchKernelGGL(k_pair, dim3(np), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;

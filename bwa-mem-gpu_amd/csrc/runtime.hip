@@ -277,7 +277,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t,
 	                   &c->d_ctg_names, &c->d_ctg_name_off, &c->d_ctg_anno, &c->d_ctg_anno_off, &c->d_rg, &c->d_qual, &c->d_qual_off, &c->d_names, &c->d_name_off, &c->d_comments, &c->d_comment_off,
 	                   &c->d_fregs, &c->d_fregs2, &c->d_fscr, &c->d_need, &c->d_xa_owner, &c->d_freg_n, &c->d_npri, &c->d_task_n, &c->d_rec_n, &c->d_task_base, &c->d_tasks, &c->d_aln_of_reg, &c->d_alns,
-	                   &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
+	                   &c->d_resc_flag, &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
 	                   &c->d_hist, &c->d_pair_tab, &c->d_nb, &c->d_pe_cap, &c->d_pe_base, &c->d_pe_regs, &c->d_pe_n, &c->d_pe_tmp, &c->d_pe_keys, &c->d_pe_idx, &c->d_resc, &c->d_ms_slab, &c->d_pe_read, &c->d_sw_cnt, &c->d_sw_base, &c->d_sw_res, &c->d_sw_tasks, &c->d_sw_info, &c->d_task_lists };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
