@@ -344,7 +344,8 @@ class Context:
     @staticmethod
     def stage_names():
         return ["k_smem(passes 1-2)+k_smem_heavy+k_smem3(pass 3)+k_intv_sort", "k_seeds", "k_chain(+k_chain_big,k_chain_flt)", "k_seed_sw (only with -W / reads > 700 bp)",
-                "k_extend_spec+k_extend(+k_extend_big, dedup/patch)", "PE: k_pestat+k_matesw (insert sizes, mate rescue)", "k_mark (mark primary) + PE: k_pair (pairing)",
+                "k_extend_spec+k_extend(+k_extend_big, dedup/patch)", "pe_rescue = PE: k_pestat + k_pe_prepare + k_pe_copy (insert sizes, lists; the rescue kernels k_matesw_sw / k_matesw start on the second stream)",
+                "k_mark (mark primary) + PE: k_pair (pairing) beside the rescue kernels, then both for the rescued pairs",
                 "k_cigar (mem_reg2aln: mapQ, CIGAR by ksw_global2 backtrack, NM/MD)", "k_sam size + scan + write (SAM text)"]
 
     @staticmethod
