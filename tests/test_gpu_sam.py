@@ -262,3 +262,65 @@ def test_files_through_the_product_reader(ctx, small_index, tmp_path):
         assert n_batches >= 4 and n_processed == 750 * len(files)
         body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
         assert b"".join(got) == body(want)
+
+
+def test_reads_inside_a_large_repeat_family(built, tmp_path):
+    """Reads from a 400-bp unit that occurs 700 times (2 % diverged copies) in a 3 Mbp genome: hundreds of chains and regions per read.
+    These reads take the heavy-read paths -- k_smem_heavy, k_chain_big / k_chain_flt, k_extend_spec, the bitonic index sorts of k_mark and
+    k_pair (lists over 128 regions), mark_core in kept-region order -- which ordinary reads never reach; SAM with -a (every hit printed)
+    and without, SE and PE, must equal the CPU path's."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    L = 3000000
+    g = rng.integers(0, 4, L, dtype=np.uint8)
+    unit = rng.integers(0, 4, 400, dtype=np.uint8)
+    starts = np.sort(rng.choice(np.arange(1000, L - 1400, 1400), 700, replace=False))
+    for s in starts:
+        c = unit.copy()
+        m = rng.random(400) < 0.02
+        c[m] = (c[m] + rng.integers(1, 4, int(m.sum()))) % 4
+        g[s:s + 400] = c
+    fa = str(tmp_path / "rep.fa")
+    seq = b"ACGT"
+    txt = bytes(np.frombuffer(seq, dtype=np.uint8)[g])
+    with open(fa, "wb") as f:
+        f.write(b">rep\n")
+        for i in range(0, L, 60):
+            f.write(txt[i:i + 60] + b"\n")
+    prefix = str(tmp_path / "rep")
+    bw.make_index(fa, prefix)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    def fq(path, reads):
+        with open(path, "wb") as f:
+            for i, r in enumerate(reads):
+                f.write(b"@h%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    r1, r2 = [], []
+    for i in range(60):
+        s = int(starts[rng.integers(0, 700)])
+        if i % 3 == 0:                                              # fragment inside the repeat unit and its unique flank
+            a = s + int(rng.integers(0, 200)); frag = txt[a:a + 420]
+        else:                                                       # fragment wholly inside the unit: every copy matches
+            a = s + int(rng.integers(0, 60)); frag = txt[a:a + 330]
+        r1.append(frag[:150]); r2.append(frag[-150:].translate(comp)[::-1])
+    f1, f2 = str(tmp_path / "h_1.fq"), str(tmp_path / "h_2.fq")
+    fq(f1, r1); fq(f2, r2)
+    body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
+    with bw.Context(prefix) as c:
+        for extra, flag in (([], 0), (["-a"], 0x8)):
+            for files in ((f1,), (f1, f2)):
+                opt = bw.default_opt()
+                opt.n_threads = 4
+                opt.flag |= flag | (0x2 if len(files) == 2 else 0)
+                want = subprocess.run([common.ORACLE, "mem", "-t", "4", *extra, prefix, *files], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+                with bw.FastqReader(*files) as rd:
+                    arr, n = rd.next(10 ** 9)
+                    got = c.process_seqs_text_array(arr, n, opt)
+                assert got == body(want), f"heavy reads: SAM differs ({extra}, {len(files)} file(s))"
+                if extra:
+                    assert got.count(b"\n") > 10 * n                                   # -a: every hit above the drop ratio is a record
+        cnt = c.counters()
+        codes, off = bw.pack_reads(r1)
+        regs = common.by_read(c.run_stages(codes, off, [bw.STAGE_REGS]))
+        n_regs = max(int(regs[i][bw.STAGE_REGS][0]) for i in range(len(r1)))
+    assert cnt["max_chains"] > 128, cnt["max_chains"]
+    assert n_regs > 128, n_regs                                  # the lists the bitonic sorts of k_mark / k_pair take
