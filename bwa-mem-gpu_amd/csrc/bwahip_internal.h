@@ -214,6 +214,7 @@ struct FinLaunch {
 	// paired end: the pairs mate rescue works on are finalised in a second launch, after their rescue (which runs beside the first launch).
 	// subset 0: all reads; 1: all but the pairs flagged in resc_flag; 2: the pairs of resc_list only (grid = 2 x their number)
 	const uint8_t *resc_flag; const int *resc_pairs; int subset;
+	int read_lo;                                                // k_sam: first read of this launch (the write pass runs in two halves so that the download of the first overlaps the second)
 	uint8_t *need; int *xa_owner;                // per region slot
 	int *task_n, *rec_n;                         // per read: regions needing reg2aln; SAM records
 	// alignment tasks
@@ -239,7 +240,7 @@ int launch_task_fill(const FinLaunch &a, hipStream_t st);
 int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st);   // the tasks k_cigar listed in redo_list; big_z: grid slabs of cigar_big_slab_bytes()
 size_t cigar_big_slab_bytes();
-int launch_sam(const FinLaunch &a, bool write, hipStream_t st);
+int launch_sam(const FinLaunch &a, bool write, hipStream_t st, int read_lo = 0, int read_hi = -1);   // reads [read_lo, read_hi) (default: all)
 
 // ---- paired-end stages on the GPU (k_pair.hip): insert-size histogram, mate rescue, pairing ----
 // what the SAM stage needs to know about one read of a pair (mem_sam_pe, bwamem_pair.c:276-419)
@@ -288,7 +289,7 @@ int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
 int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st);
 int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st);   // subset 2: n_listed pairs of resc_list
 size_t matesw_slab_bytes(int64_t window);
-int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st);
+int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st, int read_lo = 0, int read_hi = -1);
 
 // K3b: mem_flt_chained_seeds on the chains k_chain / k_chain_flt left (k_seedsw.hip)
 struct SeedSwLaunch {

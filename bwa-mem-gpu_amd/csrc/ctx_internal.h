@@ -76,6 +76,7 @@ struct BatchText {
 
 struct bwahip_ctx {
 	BatchText batch_text;
+	bool want_host_sam_off = false;      // run_final copies the SAM offsets to h_sam_off ahead of the write pass (bwahip_process_seqs)
 	std::vector<int64_t> h_sam_off;      // offsets of the reads' SAM text in h_sam (bwahip_process_seqs / _text)
 	bool external_index = false;
 	bool index_resident = false;         // d_bwt / d_sa / d_pac were filled before ctx_setup (bwahip_init_rccl)
@@ -84,6 +85,7 @@ struct bwahip_ctx {
 	DevBuf d_logtab;                     // log(i), i < BWAHIP_LOGTAB_N, from the host's libm (bwamem.c:607, 974-981)         // index arrays live in caller-owned HBM (bwahip_init_device)
 	int device = 0;
 	hipStream_t stream_copy = nullptr;   // uploads that run beside the kernels (bwahip_process_seqs: names / qualities during the hot path)
+	hipEvent_t ev_sam_half = nullptr; int sam_half_reads = 0;   // run_final: recorded when the SAM text of reads [0, sam_half_reads) is written
 	hipEvent_t ev_slice[8] = {};         // bwahip_process_seqs: one per slice of the SAM download
 	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;   // stream2/3: kernels that run beside the main one (k_chain_big)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;

@@ -274,7 +274,16 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	c->total_sam = total;
 	if ((rc = c->d_sam.ensure((size_t)total + 64))) return rc;
 	f.sam = c->d_sam.as<uint8_t>();
-	if ((rc = pe ? launch_sam_pe(f, true, c->stream) : launch_sam(f, true, c->stream))) return rc;
+	if (c->want_host_sam_off) {                                 // bwahip_process_seqs: the offsets travel ahead of the write pass
+		c->h_sam_off.resize((size_t)n + 1);
+		HIP_TRY(hipMemcpyAsync(c->h_sam_off.data(), c->d_sam_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+	}
+	// the write pass in two halves (cut at an even read: mates stay together) with an event between them: a caller that downloads the text
+	// (bwahip_process_seqs) starts on the first half while the second is being written
+	c->sam_half_reads = (n / 2) & ~1;
+	if ((rc = pe ? launch_sam_pe(f, true, c->stream, 0, c->sam_half_reads) : launch_sam(f, true, c->stream, 0, c->sam_half_reads))) return rc;
+	HIP_TRY(hipEventRecord(c->ev_sam_half, c->stream));
+	if ((rc = pe ? launch_sam_pe(f, true, c->stream, c->sam_half_reads, n) : launch_sam(f, true, c->stream, c->sam_half_reads, n))) return rc;
 	if (timed) {
 		HIP_TRY(hipEventRecord(c->ev[19], c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -452,45 +461,46 @@ static int process_seqs_impl(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n
 	text_thread.join();
 	if (rc || (rc = rc_text)) return rc;
 	const double t2 = now();
-	if ((rc = run_final(ctx, opt, n_processed, pes0, false))) return rc;
+	ctx->want_host_sam_off = true;
+	rc = run_final(ctx, opt, n_processed, pes0, false);
+	ctx->want_host_sam_off = false;
+	if (rc) return rc;
 	// SAM text back through the pinned buffer, on the context's stream (a non-blocking stream: a plain hipMemcpy would not wait
 	// for the SAM kernel), in slices of reads: while slice k+1 travels, the host threads cut slice k into one malloc()ed string
 	// per read, which is what the reference's contract wants (bwamem.c:1054)
+	// SAM text back through the pinned buffer.  run_final wrote it in two halves and sent the offsets ahead: once the first half is written
+	// (ev_sam_half) its download starts on the copy stream, beside the kernel that writes the second half.  Per-read strings: in slices of reads --
+	// while slice k+1 travels, the host threads cut slice k into one malloc()ed string per read, which is what the reference's contract wants
+	// (bwamem.c:1054).  (The context's streams are non-blocking: a plain hipMemcpy would not wait for the SAM kernels.)
 	std::vector<int64_t> &soff = ctx->h_sam_off;
-	soff.resize((size_t)n + 1);
-	if ((rc = ctx->h_sam.ensure((size_t)ctx->total_sam + 1))) return rc;
+	if ((rc = ctx->h_sam.ensure((size_t)ctx->total_sam + 1))) return rc;   // (grown before run_final when the size is known from the last batch: see below)
 	char *text = (char*)ctx->h_sam.p;
-	HIP_TRY(hipMemcpyAsync(soff.data(), ctx->d_sam_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-	if (text_out) {                                               // one piece: a single copy, no per-read strings
+	HIP_TRY(hipEventSynchronize(ctx->ev_sam_half));               // first half written; the offsets arrived before that
+	const int half = ctx->sam_half_reads;
+	constexpr int SLICES = 8;
+	int64_t sl_beg[SLICES + 1];
+	for (int k = 0; k <= SLICES / 2; ++k) sl_beg[k] = (int64_t)half * k / (SLICES / 2);
+	for (int k = 0; k <= SLICES / 2; ++k) sl_beg[SLICES / 2 + k] = half + (int64_t)(n - half) * k / (SLICES / 2);
+	auto copy_slice = [&](int k, hipStream_t st) -> int {
+		const int64_t b = soff[sl_beg[k]], e = soff[sl_beg[k + 1]];
+		if (e > b) HIP_TRY(hipMemcpyAsync(text + b, (const char*)ctx->d_sam.p + b, (size_t)(e - b), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipEventRecord(ctx->ev_slice[k], st));
+		return 0;
+	};
+	for (int k = 0; k < SLICES / 2; ++k) if ((rc = copy_slice(k, ctx->stream_copy))) return rc;
+	for (int k = SLICES / 2; k < SLICES; ++k) if ((rc = copy_slice(k, ctx->stream))) return rc;
+	const int n_sl = SLICES;
+	if (text_out) {                                               // one piece: no per-read strings
+		HIP_TRY(hipStreamSynchronize(ctx->stream_copy));
 		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		const double t3 = now();
-		{
-			const size_t tot = (size_t)ctx->total_sam, piece = ((tot + 7) / 8 + 4095) & ~(size_t)4095;
-			int k = 0;
-			for (size_t at = 0; at < tot; at += piece, ++k)
-				HIP_TRY(hipMemcpyAsync(text + at, (const char*)ctx->d_sam.p + at, tot - at < piece ? tot - at : piece, hipMemcpyDeviceToHost, (k & 1) ? ctx->stream_copy : ctx->stream));
-			HIP_TRY(hipStreamSynchronize(ctx->stream_copy));
-			HIP_TRY(hipStreamSynchronize(ctx->stream));
-		}
+		const double t4 = now();
 		text[ctx->total_sam] = 0;
 		*text_out = text; *len_out = ctx->total_sam; if (off_out) *off_out = soff.data();
-		const double t4 = now();
 		par_for_chunks(n, nt, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) seqs[i].sam = nullptr; });
 		if (verbose || ctx->knobs.e2e_log)
-			fprintf(stderr, "[bwahip] process_seqs_text %d reads: codes gather+upload %.1f ms, hot path (text upload beside it) %.1f ms, finalisation+SAM on GPU %.1f ms, download %.1f ms (%lld bytes), rest %.1f ms\n",
-			        n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (long long)ctx->total_sam, (now() - t4) * 1e3);
+			fprintf(stderr, "[bwahip] process_seqs_text %d reads: codes gather+upload %.1f ms, hot path (text upload beside it) %.1f ms, finalisation+SAM on GPU and download %.1f ms (%lld bytes), rest %.1f ms\n",
+			        n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t4 - t2) * 1e3, (long long)ctx->total_sam, (now() - t4) * 1e3);
 		return 0;
-	}
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	constexpr int SLICES = 8;
-	int n_sl = 0;
-	int64_t sl_beg[SLICES + 1];
-	for (int k = 0; k <= SLICES; ++k) sl_beg[k] = (int64_t)n * k / SLICES;
-	for (int k = 0; k < SLICES; ++k) {
-		const int64_t b = soff[sl_beg[k]], e = soff[sl_beg[k + 1]];
-		if (e > b) HIP_TRY(hipMemcpyAsync(text + b, (const char*)ctx->d_sam.p + b, (size_t)(e - b), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipEventRecord(ctx->ev_slice[k], ctx->stream));
-		n_sl = k + 1;
 	}
 	const double t3 = now();
 	std::atomic<int> oom(0), hip_bad(0);

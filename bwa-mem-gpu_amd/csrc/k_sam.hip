@@ -14,7 +14,7 @@ __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_sam_se(FinLaunch a)
 {
-	const int r = blockIdx.x, l = lane();
+	const int r = (int)blockIdx.x + a.read_lo, l = lane();
 	const DevOpt &opt = a.opt;
 	const int n = a.freg_n[r];
 	const int64_t rb0 = a.reg_base[r];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_sam_pe(FinLaunch a)
 {
 	__shared__ __attribute__((aligned(16))) DevAln s_un[2];      // [0] unaligned record of this read, [1] unaligned mate (DevAln is padded to 80 bytes)
 	__shared__ const DevAln *s_unp;
-	const int r = blockIdx.x, l = lane(), rm = r ^ 1, end = r & 1;
+	const int r = (int)blockIdx.x + a.read_lo, l = lane(), rm = r ^ 1, end = r & 1;
 	const DevOpt &opt = a.opt;
 	const int n = a.freg_n[r];
 	const int64_t rb0 = a.reg_base[r], rbm = a.reg_base[rm];
@@ -186,18 +186,24 @@ __global__ __launch_bounds__(64) void k_sam_pe(FinLaunch a)
 
 } // namespace
 
-int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st)
+int launch_sam_pe(const FinLaunch &a_, bool write, hipStream_t st, int read_lo, int read_hi)
 {
-	if (a.n_reads <= 0) return 0;
-	if (write) hipLaunchKernelGGL(k_sam_pe<true>, dim3(a.n_reads), dim3(64), 0, st, a);
-	else hipLaunchKernelGGL(k_sam_pe<false>, dim3(a.n_reads), dim3(64), 0, st, a);
+	if (read_hi < 0) read_hi = a_.n_reads;
+	if (read_hi <= read_lo) return 0;
+	FinLaunch a = a_;
+	a.read_lo = read_lo;
+	if (write) hipLaunchKernelGGL(k_sam_pe<true>, dim3(read_hi - read_lo), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_sam_pe<false>, dim3(read_hi - read_lo), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
-int launch_sam(const FinLaunch &a, bool write, hipStream_t st)
+int launch_sam(const FinLaunch &a_, bool write, hipStream_t st, int read_lo, int read_hi)
 {
-	if (a.n_reads <= 0) return 0;
-	if (write) hipLaunchKernelGGL(k_sam_se<true>, dim3(a.n_reads), dim3(64), 0, st, a);
-	else hipLaunchKernelGGL(k_sam_se<false>, dim3(a.n_reads), dim3(64), 0, st, a);
+	if (read_hi < 0) read_hi = a_.n_reads;
+	if (read_hi <= read_lo) return 0;
+	FinLaunch a = a_;
+	a.read_lo = read_lo;
+	if (write) hipLaunchKernelGGL(k_sam_se<true>, dim3(read_hi - read_lo), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_sam_se<false>, dim3(read_hi - read_lo), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

@@ -158,6 +158,7 @@ int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, c
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 	for (auto &e : c->ev_slice) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&c->ev_sam_half, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -288,6 +289,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (c->stream3) (void)hipStreamDestroy(c->stream3);
 	if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
 	for (auto &e : c->ev_slice) if (e) (void)hipEventDestroy(e);
+	if (c->ev_sam_half) (void)hipEventDestroy(c->ev_sam_half);
 	if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
