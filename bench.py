@@ -377,6 +377,16 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k1, 3), "reads_per_launch": args.batch},
         }
         out["single_context"] = single
+        # the other kernels SURVEY.md 8(d) asks figures for: the SA look-up kernels against the same HBM roofline, the integer DP of the
+        # extension in cell updates per second (no roofline fraction: VALU / LDS issue bound, no MFMA work anywhere)
+        km = out["kernel_ms"]
+        sa_bytes = (64 * counters["lf"] + 8 * counters["sa"]) / n_batches
+        out["other_kernels"] = {
+            "k_seeds": {"algorithmic_GBps": round(sa_bytes / (km["k_seeds"] * 1e-3) / 1e9, 1), "frac_of_peak": round(sa_bytes / (km["k_seeds"] * 1e-3) / 8e12, 4),
+                        "what": "64 B per LF step + 8 B per SA read (bwt_sa, bwt.c:86), counted by the kernel"},
+            "k_extend": {"GCUPS": round(counters["cells"] / n_batches / ((km["k_extend"] + km["k_extend_spec"]) * 1e-3) / 1e9, 2),
+                         "what": "ksw_extend2 cell updates per second (cells counted by the kernel, k_extend + k_extend_spec time)"},
+        }
         if dbuf:
             out["schedule"] = dbuf
             out["sum_kernel_ms_over_ms_per_batch"] = round(sum(out["kernel_ms"].values()) / (ms_step / n_batches), 3)
