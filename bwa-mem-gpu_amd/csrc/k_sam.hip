@@ -92,7 +92,7 @@ __device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, 
 // SAM text of one end of a pair (mem_sam_pe's output part, bwamem_pair.c:366-385 and 397-418).  One read per wavefront; the
 // decisions come from k_pair (PeRead), the mate's best hit h[!i] is attached to every record (mate fields, MC, TLEN).
 template <bool WRITE>
-__global__ __launch_bounds__(64, (WRITE ? 5 : 8)) void k_sam_pe(FinLaunch a)   // (the size pass at 8 waves per SIMD: 1.56 -> 1.30 ms; the write pass would spill)
+__global__ __launch_bounds__(64, (WRITE ? 6 : 8)) void k_sam_pe(FinLaunch a)   // (occupancy over registers: size pass at 8 waves per SIMD 1.56 -> 1.30 ms, write pass at 6 with 48 B of spill 3.47 -> 3.27 ms)
 {
 	__shared__ __attribute__((aligned(16))) DevAln s_un[2];      // [0] unaligned record of this read, [1] unaligned mate (DevAln is padded to 80 bytes)
 	__shared__ const DevAln *s_unp;
