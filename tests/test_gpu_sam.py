@@ -191,6 +191,15 @@ def test_plain_c_caller_reproduces_golden_sam(built, tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
     assert r.stdout == exp, _first_diff(r.stdout, exp)
     assert b"\tRG:Z:grp1" in r.stdout
+    # the loop of INTEGRATION.md 1b from C: the library's reader (one file gzipped), SAM in one piece, batches alternating between a context
+    # and its clone; 9000-base batches = 60 reads at a time, cut exactly where the reference's bseq_read cuts them
+    import gzip as _gz
+    _gz.open(str(tmp_path / "pe_2.fq.gz"), "wb").write(open(str(tmp_path / "pe_2.fq"), "rb").read())
+    r = run("-F", "-t", "4", prefix, str(tmp_path / "pe_1.fq"), str(tmp_path / "pe_2.fq.gz"))
+    assert r.stdout == want_pe, _first_diff(r.stdout, want_pe)
+    r = run("-F", "-t", "4", "-K", "9000", prefix, str(tmp_path / "se.fq"))
+    assert r.stdout == want, _first_diff(r.stdout, want)
+    assert b"files 300 reads" in r.stderr or b"files " in r.stderr
 
 
 def test_comments_and_read_group(ctx, small_index, tmp_path):
