@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_seed_walk(SeedLaunch a, long long total
 		if (__ballot(have) == 0) break;
 		const bool fin = have && (k & mask) == 0;
 		const bool walk = have && !fin;
-		const uint64_t sa_v = ix.sa[fin ? k >> ix.sa_shift : 0];   // both gathers are issued before either is waited for
-		const uint64_t nk = lane_lf(ix, walk ? k : 0);
+		uint64_t sa_v = 0, nk = 0;                              // each lane issues only the gather it needs (no dummy loads of element 0: -1 %)
+		if (fin) sa_v = ix.sa[k >> ix.sa_shift];
+		if (walk) nk = lane_lf(ix, k);
 		if (fin) { a.seeds[sid].rbeg = (int64_t)(steps + sa_v); have = false; ++n_sa; }
 		if (walk) { n_lf += k != ix.primary; k = nk; ++steps; }
 	}
