@@ -425,6 +425,7 @@ __device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen,
 	int sc_next = sw.mat[ldt(i) * 5 + ldq(j)];
 	int tn = ldt(i + 1), qn = ldq(j + 1);
 	const bool mine = k <= 2 * w;
+	int pend = 0;
 	for (int s = 0; s <= steps; ++s) {
 		const int Ein = __builtin_amdgcn_update_dpp(NEG, Eout, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane k <- lane k + 1
 		const int Fin = __builtin_amdgcn_update_dpp(NEG, Fout, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane k <- lane k - 1
@@ -446,7 +447,10 @@ __device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen,
 			f -= e_ins;
 			d |= f > tI ? 2 << 4 : 0;
 			Fout = f > tI ? f : tI;
-			z[(size_t)i * n_col + (i > w ? k : j)] = (uint8_t)d;  // zi[j - beg], beg = max(0, i - w)
+			// 4 bits per cell (h source, e extended, f extended), rows 2r and 2r+1 of a diagonal in one byte at [r][k]: the lane writes the low
+			// nibble with the even row and the whole byte with the odd one (half the LDS of a byte per cell: more tasks in flight)
+			const int nib = (d & 3) | (d >> 2 & 1) << 2 | (d >> 5 & 1) << 3;
+			if (i & 1) z[(size_t)(i >> 1) * n_col + k] = (uint8_t)(pend | nib << 4); else { pend = nib; z[(size_t)(i >> 1) * n_col + k] = (uint8_t)nib; }
 			Hd = h;
 			++i; ++j;
 		}
@@ -575,11 +579,12 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			const int min_w = dl + 3;
 			w = w > min_w ? w : min_w;
 			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
-			if ((size_t)n_col * (size_t)rlen > z_cap) { fits = false; break; }
+			const bool nib_z = 2 * w + 1 <= 64;                     // band of at most 64 diagonals: 4-bit cells, two rows per byte (wave_band_trace)
+			if ((nib_z ? (size_t)((rlen + 1) >> 1) * (size_t)(2 * w + 1) : (size_t)n_col * (size_t)rlen) > z_cap) { fits = false; break; }
 			__syncthreads();
 			// the fewest columns per lane that hold the query; CPLMAX (from the longest read of the batch) bounds what is
 			// compiled in, and with it the registers of the kernel
-			if (2 * w + 1 <= 64) score = wave_band_trace(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			if (nib_z) score = wave_band_trace(sw, qp, qs, lq, tp, ts, rlen, w, m.z, 2 * w + 1);   // (row stride = diagonals of the band)
 			else if (2 * w + 1 <= 128) score = wave_band_trace2(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 2 || lq < 128) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
@@ -597,7 +602,10 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 					else { if (have) { if (nc < m.max_c) m.cig[nc] = cur; else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
 				};
 				while (i >= 0 && k >= 0) {
-					which = m.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+					if (nib_z) {
+						const int byte = m.z[(size_t)(i >> 1) * (2 * w + 1) + (k - i + w)], nb = (i & 1) ? byte >> 4 : byte & 15;
+						which = which == 0 ? (nb & 3) : which == 1 ? (nb >> 2 & 1) : (nb >> 3 & 1) << 1;
+					} else which = m.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
 					if (which == 0) { push(0, 1); --i; --k; }
 					else if (which == 1) { push(2, 1); --i; }
 					else { push(1, 1); --k; }
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
 	// their query, at most BWAHIP_MAX_READ_LEN, and have one CIGAR operation): what does not fit goes to k_cigar_big.  The
 	// kernel waits on chains of dependent LDS / global loads, so the number of tasks in flight per CU is what matters
 	constexpr bool SMALL = FAST || CPLMAX <= 3;
-	constexpr int TCAP = SMALL ? 768 : CG_MAXT, ZL = FAST ? 16 : SMALL ? 8192 : CG_ZLDS, MC = FAST ? 8 : SMALL ? 160 : CG_MAXC, MMD = SMALL ? 512 : CG_MAXMD;
+	constexpr int TCAP = SMALL ? 768 : CG_MAXT, ZL = FAST ? 16 : SMALL ? 5120 : CG_ZLDS, MC = FAST ? 8 : SMALL ? 160 : CG_MAXC, MMD = SMALL ? 512 : CG_MAXMD;
 	__shared__ uint8_t s_q[CG_MAXQ + 8];
 	__shared__ uint8_t s_t[TCAP + 8];
 	__shared__ uint8_t s_z[ZL];
