@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_task_fill(FinLaunch a)
 // ===================================================================================================
 constexpr int CG_MAXQ = BWAHIP_MAX_READ_LEN;
 constexpr int CG_MAXT = 1536;                                // reference span of a region kept in LDS
-constexpr int CG_ZLDS = 32768;                               // backtrack matrix bytes kept in LDS (reads of 192 bases and more; 8192 below)
+constexpr int CG_ZLDS = 18432;                               // backtrack matrix bytes kept in LDS for reads of 192 bases and more (5120 below); 4 bits per cell in the band kernels
 constexpr int CG_MAXC = 512;                                 // CIGAR operations staged in LDS
 constexpr int CG_MAXMD = 1024;                               // MD bytes staged in LDS
 constexpr unsigned long long CG_SLOT = 64;                   // bytes of pool every task owns (see reg2aln)
@@ -477,6 +477,7 @@ __device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen
 	int i = -k, j0 = -k - w + d0;                                // row / column of the even cell at s = 0 (negative: not yet in the matrix)
 	int tb1 = ldt(i), sc0 = sw.mat[tb1 * 5 + ldq(j0)], sc1 = sw.mat[tb1 * 5 + ldq(j0 + 1)];
 	int tn = ldt(i + 1), qa = ldq(j0 + 1), qb = ldq(j0 + 2);
+	int pend = 0;
 	auto cell = [&](int d, int ii, int jj, int sc, int ein, int fin, int &Hd, int &Eo, int &Fo) {
 		if (d <= 2 * w && ii >= 0 && ii < tlen && jj >= 0 && jj < qlen) {
 			int e = (ii >= 1 && d < 2 * w) ? ein : NEG;
@@ -494,11 +495,14 @@ __device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen
 			f -= e_ins;
 			dd |= f > tI ? 2 << 4 : 0;
 			Fo = f > tI ? f : tI;
-			z[(size_t)ii * n_col + (ii > w ? d : jj)] = (uint8_t)dd;
+			// 4 bits per cell, the lane's two diagonals of a row in one byte at [row][lane]: low nibble with the even diagonal, whole byte with the odd one
+			const int nib = (dd & 3) | (dd >> 2 & 1) << 2 | (dd >> 5 & 1) << 3;
+			if (d & 1) z[(size_t)ii * n_col + k] = (uint8_t)(pend | nib << 4); else { pend = nib; z[(size_t)ii * n_col + k] = (uint8_t)nib; }
 			Hd = h;
 		}
 	};
 	for (int s = 0; s <= steps; s += 2) {
+		pend = 0;
 		const int c0 = sc0, c1 = sc1;
 		sc0 = sw.mat[tn * 5 + qa]; sc1 = sw.mat[tn * 5 + qb];
 		tn = ldt(i + 2); qa = ldq(j0 + 2); qb = ldq(j0 + 3);
@@ -580,12 +584,13 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			w = w > min_w ? w : min_w;
 			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
 			const bool nib_z = 2 * w + 1 <= 64;                     // band of at most 64 diagonals: 4-bit cells, two rows per byte (wave_band_trace)
-			if ((nib_z ? (size_t)((rlen + 1) >> 1) * (size_t)(2 * w + 1) : (size_t)n_col * (size_t)rlen) > z_cap) { fits = false; break; }
+			const bool nib2_z = !nib_z && 2 * w + 1 <= 128;          // up to 128: 4-bit cells, a lane's two diagonals per byte (wave_band_trace2)
+			if ((nib_z ? (size_t)((rlen + 1) >> 1) * (size_t)(2 * w + 1) : nib2_z ? (size_t)rlen * (size_t)(w + 1) : (size_t)n_col * (size_t)rlen) > z_cap) { fits = false; break; }
 			__syncthreads();
 			// the fewest columns per lane that hold the query; CPLMAX (from the longest read of the batch) bounds what is
 			// compiled in, and with it the registers of the kernel
 			if (nib_z) score = wave_band_trace(sw, qp, qs, lq, tp, ts, rlen, w, m.z, 2 * w + 1);   // (row stride = diagonals of the band)
-			else if (2 * w + 1 <= 128) score = wave_band_trace2(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (nib2_z) score = wave_band_trace2(sw, qp, qs, lq, tp, ts, rlen, w, m.z, w + 1);   // (row stride = lanes of the band)
 			else if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 2 || lq < 128) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else if (CPLMAX <= 3 || lq < 192) score = wave_global_trace<(CPLMAX < 3 ? CPLMAX : 3)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
@@ -602,8 +607,10 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 					else { if (have) { if (nc < m.max_c) m.cig[nc] = cur; else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
 				};
 				while (i >= 0 && k >= 0) {
-					if (nib_z) {
-						const int byte = m.z[(size_t)(i >> 1) * (2 * w + 1) + (k - i + w)], nb = (i & 1) ? byte >> 4 : byte & 15;
+					if (nib_z || nib2_z) {
+						const int kd = k - i + w;
+						const int byte = nib_z ? m.z[(size_t)(i >> 1) * (2 * w + 1) + kd] : m.z[(size_t)i * (w + 1) + (kd >> 1)];
+						const int nb = (nib_z ? (i & 1) : (kd & 1)) ? byte >> 4 : byte & 15;
 						which = which == 0 ? (nb & 3) : which == 1 ? (nb >> 2 & 1) : (nb >> 3 & 1) << 1;
 					} else which = m.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
 					if (which == 0) { push(0, 1); --i; --k; }
