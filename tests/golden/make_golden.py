@@ -127,5 +127,39 @@ def extras():
     sh("ls", "-la", HERE)
 
 
+def fastq_cases():
+    """tests/golden/fastq: hand-made FASTA/FASTQ inputs and the batches the REFERENCE's bseq_read / kseq_read cut from them
+    (`bwaref readfq`, oracle/ref_driver.c) -- the vectors of the product's reader (csrc/fastq_reader.cpp).  Deterministic: running it again
+    reproduces the committed files byte for byte."""
+    import random
+    assert os.path.exists("/root/reference/bwamem.c") and os.access(REF, os.X_OK), "needs the reference build (make -C oracle ref)"
+    d = os.path.join(HERE, "fastq")
+    os.makedirs(d, exist_ok=True)
+    a = (b"@r1/1 first comment  two spaces\nACGTNacgtn\n+\nIIIIIIIIII\n"
+         b"@r2\tBC:Z:ACGT\tXY:i:3\r\nACGT\r\nAC\r\n+r2 again\r\nII\r\nIIII\r\n"          # CRLF, two-line sequence and quality
+         b"\n\n@r3/2\nACGTACGTAC\n+\n@IIIIIIII@\n"                                          # quality starting with '@'; empty lines between records
+         b"@r4 \nAC\n+\nII\n"                                                                   # a single blank after the name: empty comment
+         b">fa1 a fasta record\nACGT\nACGTAC\n\nGG\n"                                          # FASTA, three sequence lines and an empty one
+         b"@r5/x\n\n+\n\n"                                                                      # empty sequence; '/x' is not a read number
+         b"@r6/12\nACGTA\n+\nIIIII\n"                                                          # only the last two characters are looked at
+         b"@last\nACGTACGT\n+\nIIII")                                                          # truncated quality: the record is dropped
+    open(f"{d}/cases_1.fq", "wb").write(a)
+    b = b"".join(b"@m%d/2 mate\nTTTTGGGGCC%s\n+\n%s\n" % (i, b"A" * i, b"J" * (10 + i)) for i in range(6))      # fewer mates than reads in cases_1.fq
+    open(f"{d}/cases_2.fq", "wb").write(b)
+    random.seed(5)
+
+    def rec(i, mate):
+        l = random.randint(30, 60)
+        s = "".join(random.choice("ACGT") for _ in range(l))
+        return f"@p{i}/{mate} c{i}\n{s}\n+\n{'F' * l}\n".encode()
+    open(f"{d}/pairs_1.fq", "wb").write(b"".join(rec(i, 1) for i in range(400)))
+    with gzip.GzipFile(f"{d}/pairs_2.fq.gz", "wb", mtime=0) as g:
+        g.write(b"".join(rec(i, 2) for i in range(400)))
+    for out, chunk, files in (("cases_1.se.txt", 100000, ["cases_1.fq"]), ("cases.pe.txt", 100000, ["cases_1.fq", "cases_2.fq"]),
+                              ("pairs.pe3000.txt", 3000, ["pairs_1.fq", "pairs_2.fq.gz"]), ("pairs.se777.txt", 777, ["pairs_1.fq"])):
+        with open(f"{d}/{out}", "wb") as f:
+            sh(REF, "readfq", str(chunk), *[f"{d}/{x}" for x in files], stdout=f, stderr=subprocess.DEVNULL)
+
+
 if __name__ == "__main__":
-    extras() if len(sys.argv) > 1 and sys.argv[1] == "extras" else main()
+    {"extras": extras, "fastq": fastq_cases}.get(sys.argv[1] if len(sys.argv) > 1 else "", main)()
