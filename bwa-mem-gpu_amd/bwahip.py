@@ -103,6 +103,12 @@ def lib():
     L.bwahip_fastq_next.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.POINTER(Seq)), C.POINTER(C.c_int)]
     L.bwahip_fastq_close.argtypes = [vp]
     L.bwahip_fastq_close.restype = None
+    L.bwahip_fastq_open_mt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.bwahip_fastq_next_batch.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(C.POINTER(Seq)), C.POINTER(C.c_int)]
+    L.bwahip_fastq_batch_seqs.argtypes = [vp, C.POINTER(C.c_int)]
+    L.bwahip_fastq_batch_seqs.restype = C.POINTER(Seq)
+    L.bwahip_fastq_batch_release.argtypes = [vp]
+    L.bwahip_fastq_batch_release.restype = None
     L.bwahip_ctx_set_rg_id.argtypes = [vp, C.c_char_p]
     L.bwahip_init_device.argtypes = [C.POINTER(Bwt), C.POINTER(Bns), vp, C.c_int, C.POINTER(vp)]
     L.bwahip_destroy.argtypes = [vp]
@@ -405,15 +411,26 @@ class Context:
 class FastqReader:
     """bwahip_fastq_*: batches of a FASTA/FASTQ file (pair), plain or gzip, as bseq_read (bwa.c:191) cuts them."""
 
-    def __init__(self, path1, path2=None):
+    def __init__(self, path1, path2=None, threads=0):
         self._h = C.c_void_p()
-        _check(lib().bwahip_fastq_open(os.fsencode(path1), os.fsencode(path2) if path2 else None, C.byref(self._h)), "bwahip_fastq_open")
+        _check(lib().bwahip_fastq_open_mt(os.fsencode(path1), os.fsencode(path2) if path2 else None, threads, C.byref(self._h)), "bwahip_fastq_open_mt")
 
     def next(self, chunk_bases, keep_comments=False):
         """-> (pointer to the bseq1_t array owned by the reader, n); n == 0 at the end of the input."""
         arr, n = C.POINTER(Seq)(), C.c_int()
         _check(lib().bwahip_fastq_next(self._h, chunk_bases, 1 if keep_comments else 0, C.byref(arr), C.byref(n)), "bwahip_fastq_next")
         return arr, n.value
+
+    def next_batch(self, chunk_bases, keep_comments=False):
+        """-> (batch handle, pointer to its bseq1_t array, n): an owned batch, valid until release_batch(handle); (None, None, 0) at the end."""
+        h, arr, n = C.c_void_p(), C.POINTER(Seq)(), C.c_int()
+        _check(lib().bwahip_fastq_next_batch(self._h, chunk_bases, 1 if keep_comments else 0, C.byref(h), C.byref(arr), C.byref(n)), "bwahip_fastq_next_batch")
+        return (h, arr, n.value) if n.value else (None, None, 0)
+
+    @staticmethod
+    def release_batch(h):
+        if h:
+            lib().bwahip_fastq_batch_release(h)
 
     def close(self):
         if self._h:

@@ -159,16 +159,29 @@ typedef struct { uint64_t x[3], info; } bwahip_intv_t;              /* bwtintv_t
 
 typedef struct bwahip_ctx bwahip_ctx;
 
-/* ---- reading FASTA/FASTQ (plain or gzip) into batches: bseq_read (bwa.c:191) / kseq_read (kseq.h:176) ----------------------
- * One reader thread per file inflates and parses ahead of the caller, so the next batch is read while the GPU works on the
- * current one.  path2 != NULL: the mates' file, batches come interleaved (read i of file 1, read i of file 2); "-" = stdin. */
+/* ---- reading FASTA/FASTQ (plain, gzip or bgzip) into batches: bseq_read (bwa.c:191) / kseq_read (kseq.h:176) -------------
+ * A parallel pipeline per input file reads ahead of the caller (csrc/fastq_reader.cpp): plain files are mmap()ed and parsed in
+ * chunks by n_threads workers, gzip streams are inflated on their own thread with the parse workers behind it, BGZF (bgzip)
+ * members are inflated by the workers in parallel; anything that is not plain four-line FASTQ goes through an exact, sequential
+ * restatement of kseq_read.  path2 != NULL: the mates' file, batches come interleaved (read i of file 1, read i of file 2);
+ * "-" = stdin.  n_threads <= 0: BWAHIP_READER_THREADS or half of the host's cores (at most 8). */
 typedef struct bwahip_fastq bwahip_fastq;
+typedef struct bwahip_fastq_batch bwahip_fastq_batch;
 int  bwahip_fastq_open(const char *path1, const char *path2, bwahip_fastq **out);
+int  bwahip_fastq_open_mt(const char *path1, const char *path2, int n_threads, bwahip_fastq **out);
 /* Next batch: reads until it holds at least chunk_bases bases and an even number of reads (bwa.c:216; `bwa mem -K`).  *n = 0 at
  * the end of the input.  name/comment/seq/qual of (*seqs)[i] point into the reader's memory and stay valid until the next call
  * or bwahip_fastq_close -- unlike bseq_read's they are NOT the caller's to free; seqs[i].sam (set by bwahip_process_seqs) is.
- * keep_comments = 0 drops FASTQ comments (stock behaviour without -C).  Names lose a trailing "/[0-9]" (bwa.c:73). */
+ * keep_comments = 0 drops FASTQ comments (stock behaviour without -C).  Names lose a trailing "/[0-9]" (bwa.c:73).
+ * A damaged input (corrupt or truncated gzip data) returns BWAHIP_EIO -- the reference's err_gzread (utils.c:142) is fatal --
+ * never a silently shortened batch. */
 int  bwahip_fastq_next(bwahip_fastq *r, int64_t chunk_bases, int keep_comments, bwahip_seq_t **seqs, int *n);
+/* The same batch as an owned object: it stays valid (with its strings) until bwahip_fastq_batch_release, independently of
+ * later batches and of the reader, so that several batches can be in flight on several contexts.  *batch = NULL and *n = 0 at
+ * the end of the input.  seqs may be NULL (bwahip_fastq_batch_seqs returns the array later). */
+int  bwahip_fastq_next_batch(bwahip_fastq *r, int64_t chunk_bases, int keep_comments, bwahip_fastq_batch **batch, bwahip_seq_t **seqs, int *n);
+bwahip_seq_t *bwahip_fastq_batch_seqs(bwahip_fastq_batch *b, int *n);
+void bwahip_fastq_batch_release(bwahip_fastq_batch *b);
 void bwahip_fastq_close(bwahip_fastq *r);
 
 /* ---- lifetime ------------------------------------------------------------
