@@ -66,6 +66,12 @@ class PeStat(C.Structure):
     _fields_ = [("low", C.c_int), ("high", C.c_int), ("failed", C.c_int), ("avg", C.c_double), ("std", C.c_double)]
 
 
+class StreamStats(C.Structure):  # bwahip_stream_t
+    _fields_ = [("chunk_bases", C.c_int64), ("max_reads", C.c_int64), ("keep_comments", C.c_int), ("reader_threads", C.c_int),
+                ("n_reads", C.c_int64), ("n_batches", C.c_int64), ("sam_bytes", C.c_int64), ("seconds", C.c_double),
+                ("reader_wait_s", C.c_double), ("gpu_busy_s", C.c_double), ("write_s", C.c_double)]
+
+
 ERRORS = {0: "ok", -1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "EIO", -5: "ECAPACITY", -6: "EINTERNAL"}
 
 STAGE_INTV, STAGE_CHAIN, STAGE_CHAIN_FLT, STAGE_REGS, STAGE_REGS_PRE, STAGE_SEEDS = 1, 2, 3, 4, 5, 6
@@ -98,6 +104,8 @@ def lib():
     L.bwahip_rccl_unique_id.argtypes = [vp]
     L.bwahip_init_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.bwahip_ctx_clone.argtypes = [vp, C.POINTER(vp)]
+    L.bwahip_ctx_clone_on.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.bwahip_stream_run.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Opt), C.POINTER(PeStat), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(StreamStats)]
     L.bwahip_process_seqs_text.argtypes = [vp, C.POINTER(Opt), C.c_int64, C.c_int, C.POINTER(Seq), C.c_void_p, C.POINTER(C.c_char_p), i64p, C.POINTER(i64p)]
     L.bwahip_fastq_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.bwahip_fastq_next.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.POINTER(Seq)), C.POINTER(C.c_int)]
@@ -223,6 +231,13 @@ class Context:
         """A further context on the same GPU sharing this one's index in HBM (bwahip_ctx_clone); keep `self` alive longer."""
         other = Context(None)
         _check(lib().bwahip_ctx_clone(self._h, C.byref(other._h)), "bwahip_ctx_clone")
+        other._keep = self
+        return other
+
+    def clone_on(self, device):
+        """A context on another GPU with its own copy of the index, made device to device (bwahip_ctx_clone_on)."""
+        other = Context(None)
+        _check(lib().bwahip_ctx_clone_on(self._h, device, C.byref(other._h)), "bwahip_ctx_clone_on")
         other._keep = self
         return other
 
@@ -442,6 +457,18 @@ class FastqReader:
 
     def __exit__(self, *a):
         self.close()
+
+
+def stream_run(ctxs, fq1, fq2=None, out_fd=-1, opt=None, chunk_bases=0, max_reads=0, keep_comments=False, reader_threads=0, pes0=None):
+    """bwahip_stream_run: FASTQ files -> SAM text on out_fd over the given contexts (the library's own reader, workers and writer;
+    no Python in the data path).  Returns the filled StreamStats."""
+    opt = opt or default_opt()
+    st = StreamStats()
+    st.chunk_bases, st.max_reads, st.keep_comments, st.reader_threads = chunk_bases, max_reads, int(keep_comments), reader_threads
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().bwahip_stream_run(arr, len(ctxs), C.byref(opt), C.byref(pes0) if pes0 is not None else None, os.fsencode(fq1),
+                                   os.fsencode(fq2) if fq2 else None, out_fd, C.byref(st)), "bwahip_stream_run")
+    return st
 
 
 def _tool(name):

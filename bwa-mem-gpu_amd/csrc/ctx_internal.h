@@ -112,7 +112,8 @@ struct bwahip_ctx {
 	DevBuf d_task_lists;                 // k_cigar's two work lists (no-DP tasks, DP tasks)
 	DevBuf d_resc_flag;                  // one byte per pair: mate rescue works on it (finalised by the second k_mark / k_pair launch)
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
-	HostBuf h_stage, h_sam;               // pinned staging: batch text in, SAM text out
+	HostBuf h_stage, h_sam, h_sam2;       // pinned staging: batch text in, SAM text out (two buffers taken in turn by bwahip_process_seqs_text)
+	int sam_flip = 0;
 	int64_t total_tasks = 0, total_sam = 0;
 	size_t pool_cap = 0;
 	float final_ms[8] = { 0 };           // k_mark, k_cigar, k_sam(size), k_sam(write) of the last run

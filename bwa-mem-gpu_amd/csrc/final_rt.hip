@@ -1,6 +1,6 @@
 // Host sequencing of the GPU finalisation (regions of mem_align1_core in HBM -> SAM text in HBM) and the C ABI entry
 // bwahip_process_seqs == mem_process_seqs (bwamem.h:69).  Kernels: k_final.hip (mark primary, selection, CIGAR/NM/MD/mapQ),
-// k_sam.hip (SAM text).  Paired-end batches still take the host path of host_final.cpp after the GPU hot path.
+// k_sam.hip (SAM text), k_pair.hip (insert sizes, mate rescue, pairing).
 #include "ctx_internal.h"
 #include <atomic>
 #include <thread>
@@ -473,8 +473,9 @@ static int process_seqs_impl(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n
 	// while slice k+1 travels, the host threads cut slice k into one malloc()ed string per read, which is what the reference's contract wants
 	// (bwamem.c:1054).  (The context's streams are non-blocking: a plain hipMemcpy would not wait for the SAM kernels.)
 	std::vector<int64_t> &soff = ctx->h_sam_off;
-	if ((rc = ctx->h_sam.ensure((size_t)ctx->total_sam + 1))) return rc;   // (grown before run_final when the size is known from the last batch: see below)
-	char *text = (char*)ctx->h_sam.p;
+	HostBuf &hs = text_out && (ctx->sam_flip ^= 1) ? ctx->h_sam2 : ctx->h_sam;   // one-piece callers: the text stays valid until the next-but-one call
+	if ((rc = hs.ensure((size_t)ctx->total_sam + 1))) return rc;
+	char *text = (char*)hs.p;
 	HIP_TRY(hipEventSynchronize(ctx->ev_sam_half));               // first half written; the offsets arrived before that
 	const int half = ctx->sam_half_reads;
 	constexpr int SLICES = 8;

@@ -249,6 +249,37 @@ int bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out)
 	return 0;
 }
 
+int bwahip_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0; }
+
+// A context on another GPU: the index arrays travel device to device (xGMI between the GPUs of a node), the new context owns its copy.
+int bwahip_ctx_clone_on(bwahip_ctx *src, int device, bwahip_ctx **out)
+{
+	if (!src || !out || !src->d_bwt.p || !src->d_sa.p || !src->d_pac.p) return BWAHIP_EINVAL;
+	if (device == src->device) return bwahip_ctx_clone(src, out);
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) { fprintf(stderr, "[bwahip] no usable HIP device (requested %d of %d)\n", device, n_dev); return BWAHIP_ENODEV; }
+	bwahip_ctx *c = new bwahip_ctx();
+	c->device = device; c->index_resident = true;
+	const size_t n_bwt = (size_t)src->host.bwt.bwt_size * 4, n_sa = (size_t)src->host.bwt.n_sa * 8, n_pac = (size_t)src->host.bns.l_pac / 4 + 1;
+	int rc = bwahip_copy_host_index(&src->host.bwt, &src->host.bns, src->host.pac, &c->host);
+	if (!rc && hipSetDevice(device) != hipSuccess) rc = BWAHIP_ENODEV;
+	if (!rc) rc = c->d_bwt.ensure(n_bwt);
+	if (!rc) rc = c->d_sa.ensure(n_sa);
+	if (!rc) rc = c->d_pac.ensure(n_pac);
+	if (!rc) {
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src->device, 0);   // already enabled is fine
+		(void)hipGetLastError();
+		if (hipMemcpyPeer(c->d_bwt.p, device, src->d_bwt.p, src->device, n_bwt) != hipSuccess || hipMemcpyPeer(c->d_sa.p, device, src->d_sa.p, src->device, n_sa) != hipSuccess ||
+		    hipMemcpyPeer(c->d_pac.p, device, src->d_pac.p, src->device, n_pac) != hipSuccess) { fprintf(stderr, "[bwahip] device-to-device copy of the index failed: %s\n", hipGetErrorString(hipGetLastError())); rc = BWAHIP_ENODEV; }
+	}
+	if (!rc) rc = ctx_setup(c, &c->host.bwt, &c->host.bns, c->host.pac);
+	if (rc) { bwahip_destroy(c); return rc; }
+	c->knobs = src->knobs; c->intv_cap = src->knobs.intv_cap; c->rg_id = src->rg_id;
+	*out = c;
+	return 0;
+}
+
 int bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out)
 {
 	if (!prefix || !out) return BWAHIP_EINVAL;
@@ -282,7 +313,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_hist, &c->d_pair_tab, &c->d_nb, &c->d_pe_cap, &c->d_pe_base, &c->d_pe_regs, &c->d_pe_n, &c->d_pe_tmp, &c->d_pe_keys, &c->d_pe_idx, &c->d_resc, &c->d_ms_slab, &c->d_pe_read, &c->d_sw_cnt, &c->d_sw_base, &c->d_sw_res, &c->d_sw_tasks, &c->d_sw_info, &c->d_task_lists };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
-	c->h_stage.release(); c->h_sam.release();
+	c->h_stage.release(); c->h_sam.release(); c->h_sam2.release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);

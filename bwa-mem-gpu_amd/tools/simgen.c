@@ -95,6 +95,78 @@ void simgen_add_repeats(uint64_t seed, int64_t len, char *seq)
 	}
 }
 
+/* "human-like" repeat load (bench.py --genome-profile human-like): what GRCh38 brings and the default profile lacks -- a large share of
+ * the bases inside dispersed families with 10^4..10^6 copies genome-wide, every copy 5..15 % diverged from its family's consensus, plus
+ * satellite arrays.  The consensus sequences depend on `family_seed` only, so every contig of a genome carries the SAME families (the copy
+ * numbers below are per base of contig: a 3.1 Gbp genome gets ~1.2 M Alu-like, ~0.9 M L1-like fragments, 20 x ~10^4 mid-frequency copies;
+ * 15 % of the Alu- and L1-like copies are young ones at 1..5 %):
+ *   Alu-like   8 subfamilies (300 bp, 2-4 % apart), 11 % of the bases, full length copies;
+ *   L1-like    4 subfamilies (6 000 bp), 26 % of the bases, 5'-truncated copies (the 3' end, length ~ 100 + Exp(900), at most 6 000);
+ *   mid        20 families of 500 bp, 0.16 % of the bases each (~10^4 copies per 3.1 Gbp);
+ *   satellite  two arrays per contig of a 171 bp unit (alpha-satellite-like), 1.5 % of the contig each, copies 1-3 % diverged;
+ * then the default profile's tandem repeats and N holes.  Insertions overwrite what is there (nested repeats, as in a real genome). */
+static void sg_consensus(uint64_t seed, int len, char *out) { simgen_random_bases(seed, len, out); }
+static void sg_insert_copy(sg_rng *r, char *seq, int64_t dst, const char *cons, int L, int div_ppm, int rc)
+{
+	int i;
+	for (i = 0; i < L; ++i) {
+		char c = rc ? cons[L - 1 - i] : cons[i];
+		if (rc) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+		if (sg_below(r, 1000000) < (uint64_t)div_ppm) {
+			uint64_t u = sg_below(r, 20);
+			if (u == 0) continue;                                   /* 1 in 20 differences is a deleted base (the copy gets shorter) */
+			c = "ACGT"[sg_next(r) & 3];
+		}
+		seq[dst++] = c;
+	}
+}
+/* divergence of one copy from its consensus: 85 % of the copies 5-15 %, 15 % young copies at 1-5 % */
+static int sg_div(sg_rng *r) { return sg_below(r, 100) < 15 ? 10000 + (int)sg_below(r, 40000) : 50000 + (int)sg_below(r, 100000); }
+void simgen_add_human_repeats(uint64_t family_seed, uint64_t seed, int64_t len, char *seq)
+{
+	enum { N_ALU = 8, L_ALU = 300, N_L1 = 4, L_L1 = 6000, N_MID = 20, L_MID = 500, L_SAT = 171 };
+	static char alu[N_ALU][L_ALU], l1[N_L1][L_L1], mid[N_MID][L_MID], sat[2][L_SAT];
+	sg_rng fr = { family_seed ^ 0xa17a17a17ULL }, r = { seed ^ 0x2545f491ULL };
+	int64_t k, n;
+	int i, f;
+	if (len < 100000) return;
+	/* consensus sequences (the same for every contig) */
+	sg_consensus(family_seed + 11, L_ALU, alu[0]);
+	for (f = 1; f < N_ALU; ++f) { memcpy(alu[f], alu[0], L_ALU); for (i = 0; i < L_ALU; ++i) if (sg_below(&fr, 100) < 3) alu[f][i] = "ACGT"[sg_next(&fr) & 3]; }
+	sg_consensus(family_seed + 13, L_L1, l1[0]);
+	for (f = 1; f < N_L1; ++f) { memcpy(l1[f], l1[0], L_L1); for (i = 0; i < L_L1; ++i) if (sg_below(&fr, 100) < 4) l1[f][i] = "ACGT"[sg_next(&fr) & 3]; }
+	for (f = 0; f < N_MID; ++f) sg_consensus(family_seed + 100 + f, L_MID, mid[f]);
+	for (f = 0; f < 2; ++f) sg_consensus(family_seed + 200 + f, L_SAT, sat[f]);
+	/* L1-like first (oldest, longest), then mid, then Alu-like (youngest: lands inside the others too) */
+	for (n = 0; n < (int64_t)(0.26 * len); ) {
+		int L = 100 + (int)(-900.0 * log(1.0 - sg_unif(&r)));
+		if (L > L_L1) L = L_L1;
+		f = (int)sg_below(&r, N_L1);
+		sg_insert_copy(&r, seq, (int64_t)sg_below(&r, len - L), l1[f] + (L_L1 - L), L, sg_div(&r), (int)(sg_next(&r) & 1));
+		n += L;
+	}
+	for (f = 0; f < N_MID; ++f)
+		for (k = 0; k < (int64_t)(0.0016 * len / L_MID); ++k)
+			sg_insert_copy(&r, seq, (int64_t)sg_below(&r, len - L_MID), mid[f], L_MID, 50000 + (int)sg_below(&r, 100000), (int)(sg_next(&r) & 1));
+	for (k = 0; k < (int64_t)(0.11 * len / L_ALU); ++k)
+		sg_insert_copy(&r, seq, (int64_t)sg_below(&r, len - L_ALU), alu[sg_below(&r, N_ALU)], L_ALU, sg_div(&r), (int)(sg_next(&r) & 1));
+	for (f = 0; f < 2; ++f) {
+		int64_t span = (int64_t)(0.015 * len) / L_SAT * L_SAT, at = (int64_t)sg_below(&r, len - span - L_SAT);
+		for (k = 0; k < span; k += L_SAT) sg_insert_copy(&r, seq, at + k, sat[f], L_SAT, 10000 + (int)sg_below(&r, 20000), 0);
+	}
+	/* tandem repeats and N holes as in the default profile */
+	for (f = 0; f < 6; ++f) {
+		int unit = 2 + (int)sg_below(&r, 30), m = 10 + (int)sg_below(&r, 40);
+		int64_t at = sg_below(&r, len - (int64_t)unit * m - 1);
+		for (i = unit; i < unit * m; ++i) seq[at + i] = seq[at + i % unit];
+	}
+	for (f = 0; f < 4; ++f) {
+		int L = 1 + (int)sg_below(&r, f == 0 ? 1 : 500);
+		int64_t at = sg_below(&r, len - L);
+		for (i = 0; i < L; ++i) seq[at + i] = 'N';
+	}
+}
+
 static inline char sg_comp(char c)
 {
 	switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; }

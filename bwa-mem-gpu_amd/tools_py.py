@@ -18,6 +18,7 @@ def _simgen():
         L = C.CDLL(path)
         L.simgen_random_bases.argtypes = [C.c_uint64, C.c_int64, C.c_void_p]
         L.simgen_add_repeats.argtypes = [C.c_uint64, C.c_int64, C.c_void_p]
+        L.simgen_add_human_repeats.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
         L.simgen_reads.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p]
         _sg = L
@@ -31,15 +32,18 @@ def contig_lengths(total):
     return [base + (1 if i < total - base * n else 0) for i in range(n)]
 
 
-def make_genome(seed, lens, repeats=True):
-    """Same bytes as `simgen genome <fa> seed repeat_mode lens...` writes (ASCII ACGTN, contigs concatenated)."""
+def make_genome(seed, lens, repeats=True, profile="default"):
+    """Same bytes as `simgen genome <fa> seed repeat_mode lens...` writes (ASCII ACGTN, contigs concatenated).  profile "human-like":
+    genome-wide Alu/L1-like families of 10^4..10^6 copies at 5-15 % divergence and satellite arrays (simgen_add_human_repeats)."""
     L = _simgen()
     g = np.empty(int(sum(lens)), dtype=np.uint8)
     o = 0
     for c, ln in enumerate(lens):
         view = g[o:o + ln]
         L.simgen_random_bases(seed + 1000003 * c, ln, view.ctypes.data)
-        if repeats:
+        if repeats and profile == "human-like":
+            L.simgen_add_human_repeats(seed, seed + 7919 * c, ln, view.ctypes.data)
+        elif repeats:
             L.simgen_add_repeats(seed + 7919 * c, ln, view.ctypes.data)
         o += ln
     return g

@@ -204,6 +204,11 @@ int  bwahip_init_rccl(const char *prefix, int rank, int world, const void *id128
  * independent otherwise (own streams and batch buffers): two of them, each driven by its own host thread and taking batches in
  * turn, overlap one batch's latency-bound kernels with the other's throughput-bound ones. */
 int  bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out);
+/* A context on another GPU of the node: the three index arrays are copied device to device (hipMemcpyPeer: over xGMI where the
+ * GPUs are linked, no second pass over the files or the host copy) into HBM the new context owns; it is independent of src
+ * afterwards.  device == src's device: the same as bwahip_ctx_clone. */
+int  bwahip_ctx_clone_on(bwahip_ctx *src, int device, bwahip_ctx **out);
+int  bwahip_device_count(void);              /* HIP devices visible to the process (0 when there is none) */
 /* Convenience: read a stock `bwa index` file set <prefix>.{bwt,sa,pac,ann,amb[,alt]} (bwa.c:402 bwa_idx_load) and init. */
 int  bwahip_init_from_files(const char *prefix, int device, bwahip_ctx **out);
 void bwahip_destroy(bwahip_ctx *ctx);
@@ -232,9 +237,34 @@ int bwahip_align_batch(bwahip_ctx *ctx, const bwahip_opt_t *opt, int n, bwahip_s
 int bwahip_process_seqs(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);
 /* The same work with the batch's SAM in one piece, for a caller whose output step is a single fwrite: *sam = NUL-terminated text
  * of the whole batch in read order (*sam_len bytes), *off (may be NULL) = n + 1 offsets with read i's records at sam[off[i]..off[i+1]).
- * Both point into the context and stay valid until the next call on it; seqs[i].sam is left NULL (no malloc per read). */
+ * Both point into the context; seqs[i].sam is left NULL (no malloc per read).  *off stays valid until the next call on the context,
+ * *sam until the next-but-one (the context alternates between two pinned buffers, so that a writer thread can still be busy with
+ * batch k while batch k + 1 is processed). */
 int  bwahip_process_seqs_text(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs,
                               const bwahip_pestat_t *pes0, const char **sam, int64_t *sam_len, const int64_t **off);
+
+/* ---- the batch driver: FASTQ files in -> SAM text out -------------------------------------------------------------------
+ * What superBatchMain(ktp_aux_t*) (cuda/superbatch_process.h:35, superbatch_process.cpp:133: read || process, double buffered,
+ * one GPU) and process()/kt_pipeline (fastmap.c:46,307: bseq_read -> mem_process_seqs -> fputs) are in the reference, for any
+ * number of contexts: one reader (bwahip_fastq_*), one host thread per context taking whole batches with their true
+ * n_processed, one writer emitting the SAM text in input order to out_fd (< 0: the text is produced and dropped).  ctxs: n_ctx
+ * contexts -- on different devices (bwahip_ctx_clone_on), or several on one device (bwahip_ctx_clone; two per device overlap one
+ * batch's serial tails with the other's kernels).  fq2 != NULL: paired-end (MEM_F_PE is set).  opt->n_threads is the host-thread
+ * budget of the run for batch staging (divided among the contexts).  Fill the first four fields of *st (0 = defaults); the rest
+ * is written on return.  The SAM header is the caller's (bwa_print_sam_hdr, bwa.c:520).  Returns the first error of any stage. */
+typedef struct {
+	int64_t chunk_bases;      /* in: bases per batch, bwa mem -K (actual_chunk_size, fastmap.c:304); <= 0: opt->chunk_size * opt->n_threads */
+	int64_t max_reads;        /* in: > 0: stop at the first batch boundary at or after this many reads */
+	int keep_comments;        /* in: -C */
+	int reader_threads;       /* in: parse threads of the reader; <= 0: default */
+	int64_t n_reads, n_batches, sam_bytes;   /* out */
+	double seconds;           /* out: opening the files -> last SAM byte written */
+	double reader_wait_s;     /* out: summed over the workers: time spent waiting for the reader */
+	double gpu_busy_s;        /* out: summed over the workers: time inside bwahip_process_seqs_text */
+	double write_s;           /* out: time the writer spent in write() */
+} bwahip_stream_t;
+int bwahip_stream_run(bwahip_ctx *const *ctxs, int n_ctx, const bwahip_opt_t *opt, const bwahip_pestat_t *pes0,
+                      const char *fq1, const char *fq2, int out_fd, bwahip_stream_t *st);
 
 /* Insert-size statistics (mem_pestat_t[4]: FF, FR, RF, RR; bwamem_pair.c:72) and mate-rescue counters ([0] local alignments
  * run, [1] regions added, [2] most alignments of one pair, [3] pairs that needed any; bwamem_pair.c:137) of the last

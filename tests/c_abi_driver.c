@@ -4,9 +4,9 @@
  *     bwahip_init (the structs a bwa_idx_load()ed index consists of)  ->  bwahip_align_batch  (== kt_for(worker1))
  *     mem_process_seqs (bwamem.h:69 signature, from libbwamem_hip.so) ->  SAM text on stdout
  * Usage: c_abi_driver [-p] [-a] [-K reads_per_batch] [-R rg_id] <prefix> <reads.fq> [mates.fq]
- *        c_abi_driver -F [-a] [-K bases_per_batch] <prefix> <reads.fq[.gz]> [mates.fq[.gz]]
- *            the loop of INTEGRATION.md 1b: bwahip_fastq_* reads the files, bwahip_process_seqs_text hands every batch's SAM over in one
- *            piece; batches alternate between a context and its bwahip_ctx_clone
+ *        c_abi_driver -F [-a] [-K bases_per_batch] [-g devices] [-c contexts_per_device] [-t host_threads] <prefix> <reads.fq[.gz]> [mates.fq[.gz]]
+ *            bwahip_stream_run, the library's batch driver (superBatchMain's role): one reader, one worker per context
+ *            (bwahip_ctx_clone_on: devices; further contexts share a device's index), SAM in input order on stdout
  * Prints the SAM body; on stderr "regs <n_reads> <n_regions> <checksum>" from the bwahip_align_batch pass. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,12 +50,14 @@ int main(int argc, char **argv)
 	bwahip_opt_t opt;
 	bwahip_ctx *loader = 0, *ctx = 0;
 	bwahip_seq_t *s1 = 0, *s2 = 0, *seqs;
-	int i, n1, n, per = 1 << 30, ai = 1, rc, files_mode = 0;
+	int i, n1, n, per = 1 << 30, ai = 1, rc, files_mode = 0, n_dev = 1, ctx_per_dev = 2;
 	bwahip_opt_init(&opt);
 	for (; ai < argc && argv[ai][0] == '-'; ++ai) {
 		if (!strcmp(argv[ai], "-p")) opt.flag |= BWAHIP_F_PE;
 		else if (!strcmp(argv[ai], "-F")) files_mode = 1;
 		else if (!strcmp(argv[ai], "-a")) opt.flag |= BWAHIP_F_ALL;
+		else if (!strcmp(argv[ai], "-g") && ai + 1 < argc) n_dev = atoi(argv[++ai]);
+		else if (!strcmp(argv[ai], "-c") && ai + 1 < argc) ctx_per_dev = atoi(argv[++ai]);
 		else if (!strcmp(argv[ai], "-K") && ai + 1 < argc) per = atoi(argv[++ai]);
 		else if (!strcmp(argv[ai], "-t") && ai + 1 < argc) opt.n_threads = atoi(argv[++ai]);
 		else if (!strcmp(argv[ai], "-R") && ai + 1 < argc) bwahip_compat_set_rg_id(argv[++ai]);
@@ -65,26 +67,28 @@ int main(int argc, char **argv)
 	/* the index as a reference program holds it after bwa_idx_load(): bwt_t, bntseq_t, pac on the host */
 	if ((rc = bwahip_init_from_files(argv[ai], 0, &loader))) { fprintf(stderr, "index load failed: %d\n", rc); return 1; }
 	if (files_mode) {
-		bwahip_ctx *second = 0, *cx[2];
-		bwahip_fastq *rd = 0;
-		bwahip_seq_t *batch; int nb, turn = 0;
-		int64_t n_processed = 0;
-		if ((rc = bwahip_ctx_clone(loader, &second))) { fprintf(stderr, "bwahip_ctx_clone failed: %d\n", rc); return 1; }
-		cx[0] = loader; cx[1] = second;
-		if ((rc = bwahip_fastq_open(argv[ai + 1], ai + 2 < argc ? argv[ai + 2] : 0, &rd))) { fprintf(stderr, "bwahip_fastq_open failed: %d\n", rc); return 1; }
-		if (ai + 2 < argc) opt.flag |= BWAHIP_F_PE;
-		while ((rc = bwahip_fastq_next(rd, per, 0, &batch, &nb)) == 0 && nb > 0) {
-			const char *sam; int64_t len; const int64_t *off;
-			if ((rc = bwahip_process_seqs_text(cx[turn ^= 1], &opt, n_processed, nb, batch, 0, &sam, &len, &off))) { fprintf(stderr, "bwahip_process_seqs_text failed: %d\n", rc); return 1; }
-			if (off[0] != 0 || off[nb] != len || sam[len] != 0) { fprintf(stderr, "inconsistent offsets\n"); return 1; }
-			fwrite(sam, 1, (size_t)len, stdout);
-			n_processed += nb;
+		/* the library's batch driver: one reader, ctx_per_dev contexts on each of n_dev devices (more devices than the box has:
+		 * further contexts on the devices it has), whole -K batches dealt with their true n_processed, SAM in input order on stdout */
+		bwahip_ctx *cx[64];
+		bwahip_stream_t st;
+		int k, n_cx = 0, have = bwahip_device_count();
+		memset(&st, 0, sizeof st);
+		st.chunk_bases = per == 1 << 30 ? 0 : per;
+		if (n_dev < 1) n_dev = 1;
+		if (ctx_per_dev < 1) ctx_per_dev = 1;
+		if (n_dev * ctx_per_dev > 64) { fprintf(stderr, "too many contexts\n"); return 2; }
+		cx[n_cx++] = loader;
+		for (k = 1; k < n_dev * ctx_per_dev; ++k) {
+			const int dev = have > 0 ? (k / ctx_per_dev) % have : 0;
+			if ((rc = bwahip_ctx_clone_on(loader, dev, &cx[n_cx]))) { fprintf(stderr, "bwahip_ctx_clone_on(%d) failed: %d\n", dev, rc); return 1; }
+			++n_cx;
 		}
-		bwahip_fastq_close(rd);
-		bwahip_destroy(second);
-		bwahip_destroy(loader);
-		fprintf(stderr, "files %lld reads\n", (long long)n_processed);
-		return rc ? 1 : 0;
+		fflush(stdout);
+		rc = bwahip_stream_run(cx, n_cx, &opt, 0, argv[ai + 1], ai + 2 < argc ? argv[ai + 2] : 0, 1, &st);
+		for (k = n_cx - 1; k >= 0; --k) bwahip_destroy(cx[k]);
+		if (rc) { fprintf(stderr, "bwahip_stream_run failed: %d\n", rc); return 1; }
+		fprintf(stderr, "files %lld reads %lld batches %d contexts %.3f s\n", (long long)st.n_reads, (long long)st.n_batches, n_cx, st.seconds);
+		return 0;
 	}
 	n1 = read_fastq(argv[ai + 1], &s1);
 	if (ai + 2 < argc) {

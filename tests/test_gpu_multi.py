@@ -63,6 +63,46 @@ def test_two_contexts_sharing_the_index_run_batches_concurrently(small_index, tm
             c1.close()
 
 
+@pytest.mark.parametrize("n_ctx", [1, 2, 3])
+def test_stream_driver_files_to_sam_over_several_contexts(small_index, tmp_path, n_ctx):
+    """bwahip_stream_run -- the product's batch driver (the role of superBatchMain, cuda/superbatch_process.cpp:133): one reader, one worker
+    per context (here clones on the one GPU; bwahip_ctx_clone_on gives the same on further devices), whole -K batches dealt with their
+    true n_processed, SAM written in input order by the writer thread.  FASTQ (plain and gzip) in, file out: must equal the CPU path's
+    output with the same -K, SE and PE, however many contexts share the work."""
+    import gzip
+    fq1, fq2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    bw.make_reads(small_index["fa"], fq1, fq2, 4300, 150, 10000, 2000, 500, 171, 20000)
+    gz1 = fq1 + ".gz"
+    with gzip.open(gz1, "wb", compresslevel=1) as g:
+        g.write(open(fq1, "rb").read())
+    K = 600 * 150                                                # 8 batches of 600 reads (PE: 4300 reads) / 4 (SE: 2150 reads)
+    want_pe = subprocess.run([common.ORACLE, "mem", "-t", "4", "-K", str(K), small_index["prefix"], fq1, fq2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    want_se = subprocess.run([common.ORACLE, "mem", "-t", "4", "-K", str(K), small_index["prefix"], fq1], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    with bw.Context(small_index["prefix"]) as c0:
+        ctxs = [c0] + [c0.clone_on(0) for _ in range(n_ctx - 1)]
+        try:
+            opt = bw.default_opt()
+            opt.n_threads = 4
+            for a, b, want in ((fq1, fq2, want_pe), (gz1, None, want_se)):
+                out = str(tmp_path / "out.sam")
+                fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    st = bw.stream_run(ctxs, a, b, fd, opt, chunk_bases=K, reader_threads=2)
+                finally:
+                    os.close(fd)
+                got = open(out, "rb").read()
+                assert got == want
+                assert st.n_reads == (4300 if b else 2150) and st.sam_bytes == len(want) and st.n_batches == (8 if b else 4)
+            # max_reads stops at a batch boundary; a missing file is an error, not an empty output
+            st = bw.stream_run(ctxs, fq1, fq2, -1, opt, chunk_bases=K, max_reads=1000)
+            assert st.n_reads == 1200 and st.n_batches == 2
+            with pytest.raises(bw.BwahipError):
+                bw.stream_run(ctxs, str(tmp_path / "missing.fq"), None, -1, opt, chunk_bases=K)
+        finally:
+            for c in ctxs[1:]:
+                c.close()
+
+
 WORKER = textwrap.dedent('''
     import os, sys
     root, prefix, fq1, fq2, batch, out = sys.argv[1:7]
