@@ -281,7 +281,7 @@ def main():
     opt = bw.default_opt()
     if pe:
         opt.flag |= 0x2
-    opt.n_threads = max(1, cpus // world)
+    opt.n_threads = max(1, int(os.environ.get("BWAHIP_BENCH_HOST_THREADS", cpus // world)))
 
     # ---------------- single_context: one batch at a time on one context (kernel_ms, roofline)
     for w in range(args.warmup):
@@ -329,7 +329,7 @@ def main():
         fqs = tp.write_fastq_fixed(os.path.join(workdir, f"bench_r{rank}"), reads, pe)
         log(f"rank {rank}: FASTQ files written ({time.time() - t0:.1f}s): {' '.join(fqs)}")
         fq2 = fqs[1] if pe else None
-        reader_threads = max(2, min(8, opt.n_threads // 2))
+        reader_threads = int(os.environ.get("BWAHIP_BENCH_READER_THREADS", max(2, min(8, opt.n_threads // 2))))
         # untimed pass 0: SAM to a file on tmpfs (kept for the parity check below); buffers grow to the batch size here
         fd = os.open(stream_sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:

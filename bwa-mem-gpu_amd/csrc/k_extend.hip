@@ -249,6 +249,216 @@ __device__ int wave_global_score(const Sw &sw, const uint8_t *q, int qs, int qle
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ksw_extend2 with a sliding column window.  The band of ksw_extend2 is trimmed after every row to the cells that are not zero
+// (ksw.c:466-469), so the live columns [beg, end] of a row are far fewer than the flank is long -- about 40 at the start of an
+// extension, growing with the score -- and they move down the diagonal.  wave_extend above gives every column of the flank a
+// register for the whole extension (qlen / 64 columns per lane, paid in every row); here lane l owns columns base + l*CPL ..
+// + CPL-1 of a window that starts at the band's first live column, with the fewest columns per lane (1..4) that hold the live
+// band.  When the band runs out of the window, or has become narrow enough for fewer columns per lane, the H / E values of
+// the live columns pass through LDS (two 16-bit values per column) and the rows go on in the instantiation that fits.  Each
+// row is evaluated exactly as in wave_extend: same cells, same order of the row-level decisions.  One thing needs care: when the band
+// grows by two columns in a row (ksw.c:469), the reference reads eh[] of a column no row has written since it was last inside the band
+// -- zeros if it was trimmed away earlier (only all-zero cells are trimmed), the first-row value if no row ever reached it.  A column
+// entering the window gets exactly that value (max_end = the rightmost column any row has written so far).
+// ---------------------------------------------------------------------------------------------------
+struct ExtSt { int i, beg, end, best, best_i, best_j, best_ie, gscore, max_off, max_end, hi; };   // hi: last column whose eh[] value sits in s_he
+__device__ __forceinline__ void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }   // one wavefront per workgroup: orders its LDS traffic
+// eh[j].h of the first row (ksw.c:396-397); eh[j].e = 0
+__device__ __forceinline__ int first_row_h(int j, int qlen, int h0, int oe_ins, int e_ins)
+{
+	const int h1st = h0 > oe_ins ? h0 - oe_ins : 0;
+	if (j == 0) return h0;
+	if (j == 1) return h1st;
+	return (j <= qlen && h1st - (j - 2) * e_ins > e_ins) ? h1st - (j - 1) * e_ins : 0;
+}
+constexpr int WIN_MAX = 256;                                 // widest live band the windowed form takes (4 columns per lane)
+
+template <int CPL>
+__device__ __noinline__ int ext_rows(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
+                                     int w, int zdrop, int h0, ExtSt &S, unsigned *s_he, Work &wk)
+{
+	const int l = lane();
+	qlen = __builtin_amdgcn_readfirstlane(qlen); tlen = __builtin_amdgcn_readfirstlane(tlen); w = __builtin_amdgcn_readfirstlane(w);
+	zdrop = __builtin_amdgcn_readfirstlane(zdrop); h0 = __builtin_amdgcn_readfirstlane(h0);
+	const int oe_del = __builtin_amdgcn_readfirstlane(sw.o_del + sw.e_del), oe_ins = __builtin_amdgcn_readfirstlane(sw.o_ins + sw.e_ins);
+	const int e_del = __builtin_amdgcn_readfirstlane(sw.e_del), e_ins = __builtin_amdgcn_readfirstlane(sw.e_ins);
+	int i = __builtin_amdgcn_readfirstlane(S.i), beg = __builtin_amdgcn_readfirstlane(S.beg), end = __builtin_amdgcn_readfirstlane(S.end);
+	int best = __builtin_amdgcn_readfirstlane(S.best), best_i = __builtin_amdgcn_readfirstlane(S.best_i), best_j = __builtin_amdgcn_readfirstlane(S.best_j);
+	int best_ie = __builtin_amdgcn_readfirstlane(S.best_ie), gscore = __builtin_amdgcn_readfirstlane(S.gscore), max_off = __builtin_amdgcn_readfirstlane(S.max_off);
+	int max_end = __builtin_amdgcn_readfirstlane(S.max_end);
+	const int hi = __builtin_amdgcn_readfirstlane(S.hi);
+	const int base = beg;                                        // first column of the window: fixed for this run of rows
+	const int j0 = base + l * CPL;
+	int qv[CPL], Hs[CPL], E[CPL];
+#pragma unroll
+	for (int c = 0; c < CPL; ++c) {
+		const int j = j0 + c;
+		qv[c] = j < qlen ? q[j * qs] : 4;
+		// beyond `end`: what the reference's eh[] holds there -- zero where a row has been (trimmed cells are zero), else the first row
+		const unsigned he = j <= hi ? s_he[j - base] : j > max_end ? (unsigned)first_row_h(j, qlen, h0, oe_ins, e_ins) : 0u;
+		Hs[c] = (int)(he & 0xffffu); E[c] = (int)(he >> 16);
+	}
+	int scn[CPL];
+	{
+		const int tb0 = i < tlen ? t[i * ts] : 4;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) scn[c] = sw.mat[tb0 * 5 + qv[c]];
+	}
+	int status = 0;                                              // 0: the extension is over; 1: go on in another window
+	for (; i < tlen; ++i) {
+		int scv[CPL];
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) scv[c] = scn[c];
+		{
+			const int tbn = i + 1 < tlen ? t[(i + 1) * ts] : 4;
+#pragma unroll
+			for (int c = 0; c < CPL; ++c) scn[c] = sw.mat[tbn * 5 + qv[c]];
+		}
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		max_end = max_end > end ? max_end : end;
+		int h1 = 0;
+		if (beg == 0) { h1 = h0 - (sw.o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+		wk.cells += end > beg ? (unsigned)(end - beg) : 0u;
+		if (CPL == 1) ++wk.rows1; else ++wk.rowsN;
+		int M[CPL], u[CPL], P = NEG;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			M[c] = Hs[c] ? Hs[c] + scv[c] : 0;
+			int tI = M[c] - oe_ins; tI = tI > 0 ? tI : 0;
+			u[c] = inb ? tI + j * e_ins : NEG;
+			P = P > u[c] ? P : u[c];
+		}
+		int run = wscan_excl_max(P, NEG);
+		int h[CPL], key = -1, firstnz = 1 << 30, lastnz = -1;
+#pragma unroll
+		for (int c = 0; c < CPL; ++c) {
+			const int j = j0 + c;
+			const bool inb = j >= beg && j < end;
+			const int f = j == beg ? 0 : run - (j - 1) * e_ins;
+			int hv = M[c] > E[c] ? M[c] : E[c];
+			hv = hv > f ? hv : f;
+			h[c] = inb ? hv : 0;
+			if (inb) {
+				int tD = M[c] - oe_del; tD = tD > 0 ? tD : 0;
+				int en = E[c] - e_del; en = en > tD ? en : tD;
+				E[c] = en;
+				const int k = hv * 1024 + j;
+				key = key > k ? key : k;
+			}
+			run = run > u[c] ? run : u[c];
+		}
+		const int up = __builtin_amdgcn_update_dpp(0, h[CPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+#pragma unroll
+		for (int c = CPL - 1; c >= 0; --c) {
+			const int j = j0 + c;
+			const int left = c == 0 ? up : h[c - 1];
+			if (j == beg) Hs[c] = h1;
+			else if (j > beg && j <= end) Hs[c] = left;
+			if (j == end) E[c] = 0;
+			if (j >= beg && j <= end && (Hs[c] != 0 || E[c] != 0)) { firstnz = firstnz < j ? firstnz : j; lastnz = lastnz > j ? lastnz : j; }
+		}
+		key = wmax(key);
+		const int m = key < 0 ? 0 : key >> 10, mj = key < 0 ? -1 : key & 1023;
+		if (end == qlen) {
+			int hend = 0;
+#pragma unroll
+			for (int c = 0; c < CPL; ++c) if ((end - base) % CPL == c) hend = __builtin_amdgcn_readlane(Hs[c], (end - base) / CPL);
+			if (end == beg) hend = h1;
+			best_ie = gscore > hend ? best_ie : i;
+			gscore = gscore > hend ? gscore : hend;
+		}
+		if (m == 0) break;
+		if (m > best) {
+			best = m; best_i = i; best_j = mj;
+			const int off = mj > i ? mj - i : i - mj;
+			max_off = max_off > off ? max_off : off;
+		} else if (zdrop > 0) {
+			if (i - best_i > mj - best_j) {
+				if (best - m - ((i - best_i) - (mj - best_j)) * e_del > zdrop) break;
+			} else {
+				if (best - m - ((mj - best_j) - (i - best_i)) * e_ins > zdrop) break;
+			}
+		}
+		const unsigned long long nzm = __ballot(lastnz >= 0);
+		int fz = end, lz = -1;
+		if (nzm) {
+			fz = __builtin_amdgcn_readlane(firstnz, __ffsll((long long)nzm) - 1);
+			lz = __builtin_amdgcn_readlane(lastnz, 63 - __clzll((long long)nzm));
+			fz = fz < end ? fz : end;
+		}
+		const int nbeg = fz;
+		if (lz < nbeg) lz = nbeg - 1;
+		beg = nbeg;
+		end = lz + 2 < qlen ? lz + 2 : qlen;
+		// the window: column `end` needs a lane (it grows by one column per row at most: old_end was inside), and a band that has become
+		// narrow enough for fewer columns per lane moves on to that instantiation (with slack, so that it does not come straight back)
+		if (end - base > 64 * CPL - 1 || (CPL > 1 && end - beg + 1 <= 64 * (CPL - 1) - 16)) {
+			if (i + 1 < tlen) {
+				// a lane's registers hold eh[] of its columns as the reference's array would: live values up to this row's `end`, beyond it
+				// what they were loaded with (see above); columns past the window's last lane are filled in by the next run's load
+#pragma unroll
+				for (int c = 0; c < CPL; ++c) {
+					const int j = j0 + c;
+					if (j >= beg && j <= end) s_he[j - beg] = ((unsigned)Hs[c] & 0xffffu) | (unsigned)E[c] << 16;
+				}
+				S.hi = end < base + 64 * CPL - 1 ? end : base + 64 * CPL - 1;
+				status = 1; ++i;
+				break;
+			}
+		}
+	}
+	S.max_end = max_end;
+	S.i = i; S.beg = beg; S.end = end; S.best = best; S.best_i = best_i; S.best_j = best_j; S.best_ie = best_ie; S.gscore = gscore; S.max_off = max_off;
+	return status;
+}
+
+// The driver: first row of ksw_extend2 (ksw.c:396-397), band clamp (ksw.c:399-407), then runs of rows in the window that fits.
+// Flanks of fewer than 64 bases keep the plain one-column-per-lane form (nothing to gain there); so do bands wider than WIN_MAX
+// columns (-w above 127) and scores that do not fit 16 bits.
+template <int CPL>
+__device__ __forceinline__ int wave_extend_fit(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
+                                               int w, int end_bonus, int zdrop, int h0, int &qle, int &tle, int &gtle, int &gscore, int &max_off, Work &wk, unsigned *s_he)
+{
+	if (qlen < 64) return wave_extend<1>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	const int e_ins = sw.e_ins, e_del = sw.e_del;
+	int wc = w;                                                  // ksw.c:399-407
+	{
+		int max_ins = div_plus1_trunc(qlen * sw.mx + end_bonus - sw.o_ins, e_ins);
+		max_ins = max_ins > 1 ? max_ins : 1;
+		wc = wc < max_ins ? wc : max_ins;
+		int max_del = div_plus1_trunc(qlen * sw.mx + end_bonus - sw.o_del, e_del);
+		max_del = max_del > 1 ? max_del : 1;
+		wc = wc < max_del ? wc : max_del;
+	}
+	const int end0 = qlen < wc + 1 ? qlen : wc + 1;              // row 0 reads columns [0, end0) and writes column end0
+	if (end0 + 1 > WIN_MAX - 8 || h0 + qlen * sw.mx >= 32760) {
+		if (CPL > 2 && qlen < 128) return wave_extend<2>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+		if (CPL > 3 && qlen < 192) return wave_extend<3>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+		if (CPL > 4 && qlen < 256) return wave_extend<4>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+		return wave_extend<CPL>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	}
+	ExtSt S;
+	S.i = 0; S.beg = 0; S.end = end0; S.best = h0; S.best_i = -1; S.best_j = -1; S.best_ie = -1; S.gscore = -1; S.max_off = 0;
+	S.max_end = -1; S.hi = -1;                                   // nothing in s_he yet: every column starts from the first row (ksw.c:396-397)
+	while (S.i < tlen) {
+		const int width = S.end - S.beg + 1;
+		int st;
+		if (width + 8 <= 64) st = ext_rows<1>(sw, q, qs, qlen, t, ts, tlen, wc, zdrop, h0, S, s_he, wk);
+		else if (width + 8 <= 128) st = ext_rows<2>(sw, q, qs, qlen, t, ts, tlen, wc, zdrop, h0, S, s_he, wk);
+		else if (CPL <= 3 || width + 8 <= 192) st = ext_rows<3>(sw, q, qs, qlen, t, ts, tlen, wc, zdrop, h0, S, s_he, wk);   // (CPL <= 3: flanks below 192 bases)
+		else st = ext_rows<(CPL <= 3 ? 3 : 4)>(sw, q, qs, qlen, t, ts, tlen, wc, zdrop, h0, S, s_he, wk);
+		wsync();
+		if (!st) break;
+	}
+	qle = S.best_j + 1; tle = S.best_i + 1; gtle = S.best_ie + 1; gscore = S.gscore; max_off = S.max_off;
+	return S.best;
+}
+
+// ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int cal_max_gap(const DevOpt &o, int qlen)           // bwamem.c:628
 {
 	int l_del = div_plus1_trunc(qlen * o.a - o.o_del, o.e_del);
@@ -295,25 +505,12 @@ __device__ __forceinline__ bool chain_window(const DevIndex &ix, const DevOpt &o
 	return true;
 }
 
-// ksw_extend2 with the fewest columns per lane that hold the flank (qlen + 1 columns): the per-row cost grows with the
-// number of columns a lane owns, and most flanks are far shorter than the read.
-template <int CPL>
-__device__ __forceinline__ int wave_extend_fit(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
-                                               int w, int end_bonus, int zdrop, int h0, int &qle, int &tle, int &gtle, int &gscore, int &max_off, Work &wk)
-{
-	if (qlen < 64) return wave_extend<1>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-	if (CPL > 2 && qlen < 128) return wave_extend<2>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-	if (CPL > 3 && qlen < 192) return wave_extend<3>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-	if (CPL > 4 && qlen < 256) return wave_extend<4>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-	return wave_extend<CPL>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-}
-
 // Extension of one seed into an alignment region (bwamem.c:716-793): left and right ksw_extend2 with band doubling
 // (MAX_BAND_TRY = 2), clip-vs-to-end choice, seed coverage.  Needs s_q / s_t of the chain loaded.
 template <int CPL>
 __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, const uint8_t *s_q, const uint8_t *s_t, int l_query,
                                               int64_t rmax0, int tl_all, const DevSeed s, const DevChain &ch, const DevSeed *seeds, int n,
-                                              int l, Work &wk)
+                                              int l, Work &wk, unsigned *s_he)
 {
 	DevReg reg;
 	reg.rb = reg.re = 0; reg.frac_rep = 0; reg.qb = reg.qe = 0; reg.sub = reg.csub = reg.sub_n = 0; reg.seedcov = 0;
@@ -327,7 +524,7 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 			const int prev = reg.score;
 			aw0 = opt.w << i;
 			reg.score = wave_extend_fit<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                 s.len * opt.a, qle, tle, gtle, gscore, max_off, wk);
+			                                 s.len * opt.a, qle, tle, gtle, gscore, max_off, wk, s_he);
 			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
@@ -340,7 +537,7 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 			const int prev = reg.score;
 			aw1 = opt.w << i;
 			reg.score = wave_extend_fit<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                 qle, tle, gtle, gscore, max_off, wk);
+			                                 qle, tle, gtle, gscore, max_off, wk, s_he);
 			if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 		}
 		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
@@ -358,6 +555,8 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 	return reg;
 }
 
+constexpr int SPEC_NONE = -0x7fffffff - 1;                    // spec_regs[].score of a chain k_extend_spec could not take (window beyond LDS)
+
 // K4a -- reads with many chains (hundreds, inside large repeat families) would keep one wavefront busy for tens of
 // milliseconds while the rest of the GPU idles.  What k_extend must do in order is only the *decision* whether a seed
 // is extended (it looks at the regions found so far); the extension itself depends on nothing but the seed and its
@@ -369,6 +568,7 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 7 : CPL == 4 ? 4 : 1)) void k_exten
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
+	__shared__ unsigned s_he[WIN_MAX];
 	const int l = lane();
 	const DevOpt &opt = a.opt;
 	const DevIndex &ix = a.ix;
@@ -390,14 +590,17 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 7 : CPL == 4 ? 4 : 1)) void k_exten
 		const int n = ch.n;
 		if (n == 0) continue;
 		int64_t rmax0; int tl_all;
-		if (!chain_window(ix, opt, seeds, n, l_query, s_t, MAXT, l, rmax0, tl_all)) continue;   // k_extend hands the read to the large-window variant
+		if (!chain_window(ix, opt, seeds, n, l_query, s_t, MAXT, l, rmax0, tl_all)) {          // k_extend hands the read to the large-window variant
+			if (l == 0) a.spec_regs[sb + ci].score = SPEC_NONE;
+			continue;
+		}
 		// the seed k_extend takes first: largest (score, index) (bwamem.c:669-674)
 		long long best = -1;
 		for (int i = l; i < n; i += 64) { const long long key = (long long)seeds[i].score << 32 | i; best = key > best ? key : best; }
 		best = wmax64(best);
 		const DevSeed s = seeds[(int)(best & 0xffffffff)];
 		__syncthreads();
-		const DevReg reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, wk);
+		const DevReg reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, wk, s_he);
 		if (l == 0) a.spec_regs[sb + ci] = reg;
 	}
 	if (l == 0 && wk.cells) { atomicAdd(&cnt_row(a.counters)[CNT_CELLS], wk.cells); atomicAdd(&cnt_row(a.counters)[CNT_ROWS1], (unsigned long long)wk.rows1); atomicAdd(&cnt_row(a.counters)[CNT_ROWSN], (unsigned long long)wk.rowsN); }
@@ -420,7 +623,7 @@ __global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *it
 // by up to opt.w per merged seed, bwamem.c:203-217, so the window has no small bound; a wide -w widens it too).
 constexpr int BIG_T = BWAHIP_EXT_BIG_T;
 template <int CPL, bool BIGT>
-__device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uint8_t *s_q, uint8_t *s_t, int8_t *s_mat, int *s_stk)
+__device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uint8_t *s_q, uint8_t *s_t, int8_t *s_mat, int *s_stk, unsigned *s_he)
 {
 	const int T_CAP = BIGT ? BIG_T : (a.lds_window < MAXT ? a.lds_window : MAXT);   // lds_window: test knob, forces the hand-over onto ordinary reads
 	const int l = lane();
@@ -449,8 +652,18 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 		const DevSeed *seeds = a.chain_seeds + sb + ch.seed_off;
 		const int n = ch.n;
 		if (n == 0) continue;
-		int64_t rmax0; int tl_all;
-		if (!chain_window(ix, opt, seeds, n, l_query, s_t, T_CAP, l, rmax0, tl_all)) {
+		// the reference window of the chain: needed by extensions only.  A many-chain read got the best seed of every chain extended ahead of
+		// time (k_extend_spec), and most of its chains have that one seed: the window (a contig look-up and a gather from the packed reference,
+		// each a chain of dependent loads) is then fetched only if this kernel extends a seed of the chain itself
+		int64_t rmax0 = 0; int tl_all = 0;
+		bool have_win = false, win_fail = false;
+		auto need_win = [&]() {
+			if (have_win) return;
+			have_win = true;
+			if (!chain_window(ix, opt, seeds, n, l_query, s_t, T_CAP, l, rmax0, tl_all)) win_fail = true;
+		};
+		if (!use_spec) need_win();
+		if (win_fail) {
 			if (l == 0) {
 				if (BIGT) { atomicExch(a.err, 3); atomicExch(a.err + 1, r); }          // window beyond BIG_T bases
 				else a.redo_list[atomicAdd(a.redo_n, 1)] = r;                          // k_extend_big redoes the read
@@ -517,8 +730,16 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 			// ---- extend (bwamem.c:716-793); the best seed of every chain of a many-chain read was extended ahead of
 			// time by k_extend_spec (its result does not depend on the regions found so far, only the decision above does)
 			DevReg reg;
-			if (use_spec && k == n - 1) reg = a.spec_regs[sb + ci];
-			else reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, wk);
+			bool from_spec = use_spec && k == n - 1;
+			if (from_spec) { reg = a.spec_regs[sb + ci]; if (reg.score == SPEC_NONE) from_spec = false; }
+			if (!from_spec) {
+				need_win();
+				if (win_fail) {
+					if (l == 0) { a.redo_list[atomicAdd(a.redo_n, 1)] = r; a.reg_n[r] = 0; }   // (use_spec implies !BIGT)
+					return;
+				}
+				reg = extend_seed<CPL>(sw, opt, s_q, s_t, l_query, rmax0, tl_all, s, ch, seeds, n, l, wk, s_he);
+			}
 			if (l == 0) av[n_av] = reg;
 			++n_av;
 			__threadfence_block();
@@ -554,10 +775,22 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 		__threadfence_block(); __syncthreads();
 		if (l == 0) for (int i = 0; i < n; ++i) av[i].n_comp = 1;
 		__threadfence_block(); __syncthreads();
-		for (int i = 1; i < n; ++i) {
+		// bwamem.c:453: an entry takes part only if it lies within max_chain_gap of its predecessor on the same contig.  That test reads rid and
+		// re, which this loop never changes, and the entry's own rb, which only its own turn changes: it is evaluated for 64 entries at a
+		// time ahead of the sequential pass, which then visits the entries that passed (a read inside a repeat family has hundreds of
+		// regions at unrelated places: nearly all of them are skipped)
+		for (int cbase = 0; cbase < n; cbase += 64) {
+		unsigned long long act_m;
+		{
+			const int ii = cbase + l;
+			bool act = false;
+			if (ii >= 1 && ii < n) act = av[ii].rid == av[ii - 1].rid && av[ii].rb < av[ii - 1].re + opt.max_chain_gap;
+			act_m = __ballot(act);
+		}
+		while (act_m) {
+			const int i = cbase + __ffsll((long long)act_m) - 1;
+			act_m &= act_m - 1;
 			DevReg p = av[i];
-			const DevReg pm = av[i - 1];
-			if (p.rid != pm.rid || p.rb >= pm.re + opt.max_chain_gap) continue;
 			bool p_dirty = false;
 			for (int j = i - 1; j >= 0; --j) {
 				DevReg q = av[j];
@@ -655,6 +888,7 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 				__threadfence_block(); __syncthreads();
 			}
 		}
+		}
 		t_lp = wall_clock64();
 		// compact, sort by (score desc, rb, qb), drop identical hits (bwamem.c:481-495)
 		{                                                       // drop the excluded entries (qe == qb), order kept: ballot compaction
@@ -716,8 +950,9 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 7 : CPL == 4 ? 4 : 1)) void k_exten
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ int s_stk[3 * 80];
+	__shared__ unsigned s_he[WIN_MAX];
 	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;   // heavy reads are scheduled first (k_order)
-	extend_read<CPL, false>(a, r, s_q, s_t, s_mat, s_stk);
+	extend_read<CPL, false>(a, r, s_q, s_t, s_mat, s_stk, s_he);
 }
 
 // the reads k_extend handed over (reference window beyond LDS): window in this workgroup's global slab
@@ -727,10 +962,11 @@ __global__ __launch_bounds__(64) void k_extend_big(ExtLaunch a)
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ int s_stk[3 * 80];
+	__shared__ unsigned s_he[WIN_MAX];
 	uint8_t *s_t = a.big_t + (size_t)blockIdx.x * (BIG_T + 64);
 	const int n_redo = *a.redo_n;
 	for (int it = (int)blockIdx.x; it < n_redo; it += (int)gridDim.x) {
-		extend_read<CPL, true>(a, a.redo_list[it], s_q, s_t, s_mat, s_stk);
+		extend_read<CPL, true>(a, a.redo_list[it], s_q, s_t, s_mat, s_stk, s_he);
 		__syncthreads();
 	}
 }
@@ -752,6 +988,7 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
+	__shared__ unsigned s_he[WIN_MAX];
 	const int r = blockIdx.x, l = lane();
 	if (r >= n) return;
 	const int *p = params + 10 * r;
@@ -765,6 +1002,10 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
 	int qle, tle, gtle, gscore, max_off;
 	Work wk = { 0, 0, 0 };
 	int sc = wave_extend<11>(sw, s_q, 1, qlen, s_t, 1, tlen, p[2], p[5], p[4], p[3], qle, tle, gtle, gscore, max_off, wk);
+	// the windowed form (what the extension kernels run for flanks of 64 bases and more) must give the same six numbers
+	int qle2, tle2, gtle2, gscore2, max_off2;
+	const int sc2 = wave_extend_fit<11>(sw, s_q, 1, qlen, s_t, 1, tlen, p[2], p[5], p[4], p[3], qle2, tle2, gtle2, gscore2, max_off2, wk, s_he);
+	if (sc2 != sc || qle2 != qle || tle2 != tle || gtle2 != gtle || gscore2 != gscore || max_off2 != max_off) sc = -777777;
 	if (l == 0) { int *o = out6 + 6 * r; o[0] = sc; o[1] = qle; o[2] = tle; o[3] = gtle; o[4] = gscore; o[5] = max_off; }
 }
 
