@@ -129,6 +129,7 @@ def lib():
     L.bwahip_batch_run.argtypes = [vp, C.POINTER(Opt), C.POINTER(C.c_float), C.c_int]
     L.bwahip_batch_counters.argtypes = [vp, u64p, C.c_int]
     L.bwahip_kernel_name.restype = C.c_char_p
+    L.bwahip_kat_introsort.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bwahip_kat_occ4.argtypes = [vp, C.c_int, vp, vp]
     L.bwahip_kat_sa.argtypes = [vp, C.c_int, vp, vp]
     L.bwahip_kat_extend.argtypes = [vp, C.c_int, vp, vp, vp]
@@ -381,6 +382,15 @@ class Context:
                  "dp_rows_1col", "dp_rows_ncol", "dedup_sort1_max", "dedup_loop_max", "dedup_sort2_max",
                  "pass3_blocks", "pass3_intv", "_26", "_27", "_28", "_29", "_30", "_31"]
         return {k: int(buf[i]) for i, k in enumerate(names)}
+
+    def kat_introsort(self, k64, score, qb, mode):
+        """(idx_par, idx_seq, ran_parallel): the wavefront's exact introsort and the one-lane restatement of ksort.h on the same keys."""
+        k64 = np.ascontiguousarray(k64, dtype=np.int64); score = np.ascontiguousarray(score, dtype=np.int32); qb = np.ascontiguousarray(qb, dtype=np.int32)
+        n = len(k64)
+        a = np.empty(n, dtype=np.int32); b = np.empty(n, dtype=np.int32); st = np.zeros(2, dtype=np.int32)
+        _check(lib().bwahip_kat_introsort(self._h, n, mode, k64.ctypes.data, score.ctypes.data, qb.ctypes.data, a.ctypes.data, b.ctypes.data, st.ctypes.data), "bwahip_kat_introsort")
+        assert st[1] == 0
+        return a, b, bool(st[0])
 
     def kat_occ4(self, k):
         k = np.ascontiguousarray(k, dtype=np.uint64)

@@ -174,6 +174,7 @@ struct ExtLaunch {
 	DevReg *spec_regs; int2 *spec_items; int *spec_n; int spec_min_chains;
 	int rank_sort_min;                           // dedup: lists at least this long try the wavefront rank sort first (shorter: one-lane introsort hides behind other wavefronts)
 	int *redo_list, *redo_n;                     // reads k_extend hands to k_extend_big (reference window beyond the LDS window)
+	int *dedup_list, *dedup_n;                   // reads k_extend leaves with more than one region: k_dedup sorts / dedups / patches them
 	uint8_t *big_t;                              // BWAHIP_EXT_BIG_GRID slabs of BWAHIP_EXT_BIG_T + 64 bytes
 	int lds_window;                              // largest reference window k_extend keeps in LDS (<= its compiled MAXT)
 };
@@ -305,6 +306,8 @@ constexpr int BWAHIP_LOGTAB_N = 65536;
 
 int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff,
                    int *out6, hipStream_t st);
+int launch_kat_isort(int n, int mode, const void *keys16, int *idx_par, int *idx_seq, int *work, int *status, hipStream_t st);
+size_t kat_isort_work_ints(int n);
 int launch_kat_occ4(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st);
 int launch_kat_sa(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st);
 int launch_kat_extend(const DevIndex &ix, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12, hipStream_t st);

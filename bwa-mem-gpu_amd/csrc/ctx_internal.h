@@ -46,7 +46,7 @@ struct Knobs {
 	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
 	int heavy_mult = 10;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never)
 	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which k_chain_big takes the read (< 0: off)
-	int rank_sort_min = 192;    // BWAHIP_RANK_SORT_MIN: dedup lists at least this long try the wavefront rank sort
+	int rank_sort_min = 2;      // BWAHIP_RANK_SORT_MIN: dedup lists at least this long are sorted by the whole wavefront (shorter: the one-lane restatement of ks_introsort)
 	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
 	int ext_lds_window = 1 << 30;   // BWAHIP_EXT_LDS_WINDOW: reference windows above this go to k_extend_big (tests; default = the compiled LDS window)
 	int gpu_final = 1;          // BWAHIP_GPU_FINAL: 0 = finalisation of single-end batches on host threads (host_final.cpp) instead of the GPU kernels
@@ -101,7 +101,7 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t, d_dedup;
 	// finalisation on the GPU (final_rt.hip)
 	DevBuf d_ctg_names, d_ctg_name_off, d_ctg_anno, d_ctg_anno_off, d_rg;      // contig names / annotations (SAM RNAME, XR), read-group id
 	DevBuf d_qual, d_qual_off, d_names, d_name_off, d_comments, d_comment_off; // per-batch text inputs of the SAM kernels

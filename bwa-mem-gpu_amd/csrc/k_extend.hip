@@ -274,7 +274,7 @@ __device__ __forceinline__ int first_row_h(int j, int qlen, int h0, int oe_ins, 
 constexpr int WIN_MAX = 256;                                 // widest live band the windowed form takes (4 columns per lane)
 
 template <int CPL>
-__device__ __noinline__ int ext_rows(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
+__device__ __forceinline__ int ext_rows(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen,
                                      int w, int zdrop, int h0, ExtSt &S, unsigned *s_he, Work &wk)
 {
 	const int l = lane();
@@ -435,12 +435,8 @@ __device__ __forceinline__ int wave_extend_fit(const Sw &sw, const uint8_t *q, i
 		wc = wc < max_del ? wc : max_del;
 	}
 	const int end0 = qlen < wc + 1 ? qlen : wc + 1;              // row 0 reads columns [0, end0) and writes column end0
-	if (end0 + 1 > WIN_MAX - 8 || h0 + qlen * sw.mx >= 32760) {
-		if (CPL > 2 && qlen < 128) return wave_extend<2>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-		if (CPL > 3 && qlen < 192) return wave_extend<3>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-		if (CPL > 4 && qlen < 256) return wave_extend<4>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	if (end0 + 1 > WIN_MAX - 8 || h0 + qlen * sw.mx >= 32760)     // (-w above 127, or scores beyond 16 bits: the plain form, every column a register)
 		return wave_extend<CPL>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
-	}
 	ExtSt S;
 	S.i = 0; S.beg = 0; S.end = end0; S.best = h0; S.best_i = -1; S.best_j = -1; S.best_ie = -1; S.gscore = -1; S.max_off = 0;
 	S.max_end = -1; S.hi = -1;                                   // nothing in s_he yet: every column starts from the first row (ksw.c:396-397)
@@ -517,32 +513,41 @@ __device__ __forceinline__ DevReg extend_seed(const Sw &sw, const DevOpt &opt, c
 	reg.n_comp = 0; reg.is_alt = 0; reg.pad = 0;
 	reg.rid = ch.rid; reg.score = reg.truesc = -1;
 	int aw0 = opt.w, aw1 = opt.w;
-	if (s.qbeg) {                                       // left extension on the reversed prefixes
-		int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
-		const int tlen = (int)(s.rbeg - rmax0);
-		for (int i = 0; i < 2; ++i) {                   // MAX_BAND_TRY
-			const int prev = reg.score;
-			aw0 = opt.w << i;
-			reg.score = wave_extend_fit<CPL>(sw, s_q + s.qbeg - 1, -1, s.qbeg, s_t + tlen - 1, -1, tlen, aw0, opt.pen_clip5, opt.zdrop,
-			                                 s.len * opt.a, qle, tle, gtle, gscore, max_off, wk, s_he);
-			if (reg.score == prev || max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+	// left extension on the reversed prefixes (bwamem.c:721-750), then the right one (bwamem.c:752-780): one loop, so that the DP code
+	// exists once per kernel
+	for (int side = 0; side < 2; ++side) {
+		const bool left = side == 0;
+		const int qe = s.qbeg + s.len, re = (int)(s.rbeg + s.len - rmax0);
+		if (left ? s.qbeg == 0 : qe == l_query) {
+			if (left) { reg.score = reg.truesc = s.len * opt.a; reg.qb = 0; reg.rb = s.rbeg; }
+			else { reg.qe = l_query; reg.re = s.rbeg + s.len; }
+			continue;
 		}
-		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
-		else { reg.qb = 0; reg.rb = s.rbeg - gtle; reg.truesc = gscore; }
-	} else { reg.score = reg.truesc = s.len * opt.a; reg.qb = 0; reg.rb = s.rbeg; }
-	if (s.qbeg + s.len != l_query) {                    // right extension
-		int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
-		const int sc0 = reg.score, qe = s.qbeg + s.len, re = (int)(s.rbeg + s.len - rmax0);
-		for (int i = 0; i < 2; ++i) {
+		const int tlen = left ? (int)(s.rbeg - rmax0) : tl_all - re;
+		const int qlen = left ? s.qbeg : l_query - qe;
+		const uint8_t *qp = left ? s_q + s.qbeg - 1 : s_q + qe;
+		const uint8_t *tp = left ? s_t + tlen - 1 : s_t + re;
+		const int st = left ? -1 : 1;
+		const int bonus = left ? opt.pen_clip5 : opt.pen_clip3;
+		const int sc0 = reg.score;                          // right side: the score the left side reached
+		const int h0 = left ? s.len * opt.a : sc0;
+		int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0, awc = opt.w;
+		for (int i = 0; i < 2; ++i) {                       // MAX_BAND_TRY
 			const int prev = reg.score;
-			aw1 = opt.w << i;
-			reg.score = wave_extend_fit<CPL>(sw, s_q + qe, 1, l_query - qe, s_t + re, 1, tl_all - re, aw1, opt.pen_clip3, opt.zdrop, sc0,
-			                                 qle, tle, gtle, gscore, max_off, wk, s_he);
-			if (reg.score == prev || max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+			awc = opt.w << i;
+			reg.score = wave_extend_fit<CPL>(sw, qp, st, qlen, tp, st, tlen, awc, bonus, opt.zdrop, h0, qle, tle, gtle, gscore, max_off, wk, s_he);
+			if (reg.score == prev || max_off < (awc >> 1) + (awc >> 2)) break;
 		}
-		if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
-		else { reg.qe = l_query; reg.re = rmax0 + re + gtle; reg.truesc += gscore - sc0; }
-	} else { reg.qe = l_query; reg.re = s.rbeg + s.len; }
+		if (left) {
+			aw0 = awc;
+			if (gscore <= 0 || gscore <= reg.score - opt.pen_clip5) { reg.qb = s.qbeg - qle; reg.rb = s.rbeg - tle; reg.truesc = reg.score; }
+			else { reg.qb = 0; reg.rb = s.rbeg - gtle; reg.truesc = gscore; }
+		} else {
+			aw1 = awc;
+			if (gscore <= 0 || gscore <= reg.score - opt.pen_clip3) { reg.qe = qe + qle; reg.re = rmax0 + re + tle; reg.truesc += reg.score - sc0; }
+			else { reg.qe = l_query; reg.re = rmax0 + re + gtle; reg.truesc += gscore - sc0; }
+		}
+	}
 	int cov = 0;                                        // seedcov (bwamem.c:782-786)
 	for (int i = l; i < n; i += 64) {
 		const DevSeed t = seeds[i];
@@ -622,7 +627,9 @@ __global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *it
 // k_extend_big, the same code with the window in a global-memory slab of BIG_T bases (tandem repeats: a chain may drift
 // by up to opt.w per merged seed, bwamem.c:203-217, so the window has no small bound; a wide -w widens it too).
 constexpr int BIG_T = BWAHIP_EXT_BIG_T;
-template <int CPL, bool BIGT>
+// PHASE 0: both parts (k_extend_big); 1: the mem_chain2aln calls only -- a read left with more than one region is listed for k_dedup (its
+// sorts and the dedup pass want other registers and run as their own launch); 2: mem_sort_dedup_patch of a listed read.
+template <int CPL, bool BIGT, int PHASE>
 __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uint8_t *s_q, uint8_t *s_t, int8_t *s_mat, int *s_stk, unsigned *s_he)
 {
 	const int T_CAP = BIGT ? BIG_T : (a.lds_window < MAXT ? a.lds_window : MAXT);   // lds_window: test knob, forces the hand-over onto ordinary reads
@@ -647,6 +654,8 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 	for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
 	__syncthreads();
 
+	if (PHASE == 2) n_av = a.reg_n[r];
+	if (PHASE != 2)
 	for (int ci = 0; ci < n_chains; ++ci) {
 		const DevChain ch = a.chains[sb + ci];
 		const DevSeed *seeds = a.chain_seeds + sb + ch.seed_off;
@@ -746,12 +755,21 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 			__syncthreads();
 		}
 	}
-	if (a.dbg_regs) {                                           // stage dump: regions before mem_sort_dedup_patch
+	if (PHASE != 2 && a.dbg_regs) {                              // stage dump: regions before mem_sort_dedup_patch
 		for (int i = l; i < n_av; i += 64) a.dbg_regs[rb0 + i] = av[i];
 		if (l == 0) a.dbg_reg_n[r] = n_av;
 	}
 
 	const unsigned long long t_1 = wall_clock64();
+	if (PHASE == 1 && n_av > 1) {                               // the list goes on to k_dedup
+		if (l == 0) {
+			a.reg_n[r] = n_av;
+			a.dedup_list[atomicAdd(a.dedup_n, 1)] = r;
+			if (wk.cells) { atomicAdd(&cnt_row(a.counters)[CNT_CELLS], wk.cells); atomicAdd(&cnt_row(a.counters)[CNT_ROWS1], (unsigned long long)wk.rows1); atomicAdd(&cnt_row(a.counters)[CNT_ROWSN], (unsigned long long)wk.rowsN); }
+			atomicMax(&cnt_row(a.counters)[14], t_1 - t_0);
+		}
+		return;
+	}
 	// ---- mem_sort_dedup_patch (bwamem.c:444-496) + is_alt (bwamem.c:1091-1095).  The scalar logic is replicated
 	// in every lane (identical reads of av[]), stores are done by lane 0; the rare banded global alignment is
 	// collective.  The sort permutes an index array; the list is then gathered into that order.
@@ -763,7 +781,10 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 		RegKey *keys = reinterpret_cast<RegKey*>(a.tmp_regs + rb0);   // the spare list is free until the gather below
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		if (n < a.rank_sort_min || !wave_rank_sort(RegSort{keys, 0}, n, idx, l)) {
+		// ks_introsort(mem_ars2): by the whole wavefront, exact also with equal keys (regsort_dev.h / isort_dev.h); the one-lane restatement
+		// only when the introsort's depth limit is reached (or the test knob asks for it).  Scratch: behind the keys in the spare list.
+		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l)) {
+			__threadfence_block(); __syncthreads();
 			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
 		}
 		__threadfence_block(); __syncthreads();
@@ -907,7 +928,8 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 		}
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].rb; keys[i].score = av[i].score; keys[i].qb = av[i].qb; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		if (n < a.rank_sort_min || !wave_rank_sort(RegSort{keys, 1}, n, idx, l)) {
+		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l)) {
+			__threadfence_block(); __syncthreads();
 			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad); }
 		}
 		__threadfence_block(); __syncthreads();
@@ -937,7 +959,8 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 	if (l == 0) {
 		a.reg_n[r] = n;
 		if (wk.cells) { atomicAdd(&cnt_row(a.counters)[CNT_CELLS], wk.cells); atomicAdd(&cnt_row(a.counters)[CNT_ROWS1], (unsigned long long)wk.rows1); atomicAdd(&cnt_row(a.counters)[CNT_ROWSN], (unsigned long long)wk.rowsN); }
-		atomicMax(&cnt_row(a.counters)[14], t_1 - t_0); atomicMax(&cnt_row(a.counters)[15], wall_clock64() - t_1);
+		if (PHASE != 2) atomicMax(&cnt_row(a.counters)[14], t_1 - t_0);
+		atomicMax(&cnt_row(a.counters)[15], wall_clock64() - t_1);
 		atomicMax(&cnt_row(a.counters)[21], t_s1 - t_1); atomicMax(&cnt_row(a.counters)[22], t_lp - t_s1); atomicMax(&cnt_row(a.counters)[23], wall_clock64() - t_lp);
 	}
 }
@@ -952,7 +975,23 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? 7 : CPL == 4 ? 4 : 1)) void k_exten
 	__shared__ int s_stk[3 * 80];
 	__shared__ unsigned s_he[WIN_MAX];
 	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;   // heavy reads are scheduled first (k_order)
-	extend_read<CPL, false>(a, r, s_q, s_t, s_mat, s_stk, s_he);
+	extend_read<CPL, false, 1>(a, r, s_q, s_t, s_mat, s_stk, s_he);
+}
+
+// mem_sort_dedup_patch of the reads k_extend listed (more than one region), one read per wavefront
+template <int CPL>
+__global__ __launch_bounds__(64) void k_dedup(ExtLaunch a)
+{
+	__shared__ uint8_t s_q[MAXQ + 8];
+	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ int8_t s_mat[32];
+	__shared__ int s_stk[3 * 80];
+	__shared__ unsigned s_he[WIN_MAX];
+	const int n_list = *a.dedup_n;
+	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
+		extend_read<CPL, false, 2>(a, a.dedup_list[it], s_q, s_t, s_mat, s_stk, s_he);
+		__syncthreads();
+	}
 }
 
 // the reads k_extend handed over (reference window beyond LDS): window in this workgroup's global slab
@@ -966,7 +1005,7 @@ __global__ __launch_bounds__(64) void k_extend_big(ExtLaunch a)
 	uint8_t *s_t = a.big_t + (size_t)blockIdx.x * (BIG_T + 64);
 	const int n_redo = *a.redo_n;
 	for (int it = (int)blockIdx.x; it < n_redo; it += (int)gridDim.x) {
-		extend_read<CPL, true>(a, a.redo_list[it], s_q, s_t, s_mat, s_stk, s_he);
+		extend_read<CPL, true, 0>(a, a.redo_list[it], s_q, s_t, s_mat, s_stk, s_he);
 		__syncthreads();
 	}
 }
@@ -1009,7 +1048,27 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
 	if (l == 0) { int *o = out6 + 6 * r; o[0] = sc; o[1] = qle; o[2] = tle; o[3] = gtle; o[4] = gscore; o[5] = max_off; }
 }
 
+// known-answer kernel: the wavefront's exact introsort (regsort_dev.h / isort_dev.h) beside the one-lane restatement of ksort.h on the same keys
+__global__ __launch_bounds__(64) void k_kat_isort(int n, int mode, const RegKey *keys, int *idx_par, int *idx_seq, int *work, int *status)
+{
+	__shared__ int s_stk[3 * 80];
+	__shared__ unsigned s_lds[256];
+	const int l = lane();
+	for (int i = l; i < n; i += 64) { idx_par[i] = i; idx_seq[i] = i; }
+	__threadfence_block(); __syncthreads();
+	const bool ok = wave_sort_exact(RegSort{keys, mode}, n, idx_par, work, s_stk, s_lds, l);
+	__threadfence_block(); __syncthreads();
+	if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, mode}, n, idx_seq, s_stk, &bad); status[0] = ok ? 1 : 0; status[1] = bad; }
+}
+
 } // namespace
+
+int launch_kat_isort(int n, int mode, const void *keys16, int *idx_par, int *idx_seq, int *work, int *status, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_kat_isort, dim3(1), dim3(64), 0, st, n, mode, reinterpret_cast<const RegKey*>(keys16), idx_par, idx_seq, work, status);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+size_t kat_isort_work_ints(int n) { return 6 * ((size_t)n / 64 + 1) + 2 * ((size_t)n / 2 + 1) + (size_t)n + (size_t)n / 4 + 4; }
 
 int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q, const int64_t *qoff, const uint8_t *t, const int64_t *toff,
                    int *out6, hipStream_t st)
@@ -1044,6 +1103,12 @@ int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_extend<4>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend<5>, dim3(a.n_reads), dim3(64), 0, st, a);
 	else hipLaunchKernelGGL(k_extend<11>, dim3(a.n_reads), dim3(64), 0, st, a);
+	// sort / dedup / patch of the reads left with more than one region
+	const int dgrid = a.n_reads < 32768 ? a.n_reads : 32768;
+	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_dedup<3>, dim3(dgrid), dim3(64), 0, st, a);
+	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_dedup<4>, dim3(dgrid), dim3(64), 0, st, a);
+	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_dedup<5>, dim3(dgrid), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_dedup<11>, dim3(dgrid), dim3(64), 0, st, a);
 	// reads whose reference window exceeded the LDS window (none on ordinary data): one generic instantiation
 	hipLaunchKernelGGL(k_extend_big<11>, dim3(BWAHIP_EXT_BIG_GRID), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;

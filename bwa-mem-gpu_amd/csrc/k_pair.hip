@@ -184,12 +184,15 @@ struct MsLds {
 
 // mem_sort_dedup_patch with bns == 0 (no patching), as mem_matesw calls it (bwamem_pair.c:203; bwamem.c:444-496).
 // L: the list (n entries), tmp: a spare list of the same capacity, keys / idx: sort scratch (n and 2n entries).
-__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp, RegKey *keys, int *idx, int *stk, int l, int *err)
+__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp, RegKey *keys, int *idx, int *stk, unsigned *lds256, int l, int *err)
 {
 	if (n <= 1) return n;
 	for (int i = l; i < n; i += 64) { keys[i].k64 = L[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 	wsync();
-	if (n < 8 || !wave_rank_sort(RegSort{keys, 0}, n, idx, l)) {
+	// the whole wavefront sorts, exactly also when keys are equal (a rescued hit that repeats one of the list: the usual case here); its
+	// scratch is the spare list, which is free while a sort runs
+	if (!wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(tmp), stk, lds256, l)) {
+		wsync();
 		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, stk, &bad); if (bad) atomicExch(err, 40 + bad); }
 	}
 	wsync();
@@ -197,10 +200,15 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 	wsync();
 	for (int i = l; i < n; i += 64) L[i] = tmp[i];
 	wsync();
-	if (l == 0) {                                                // redundancy (bwamem.c:451-480 without the patch branch)
-		for (int i = 1; i < n; ++i) {
+	// redundancy (bwamem.c:451-480 without the patch branch).  The test that lets an entry take part (bwamem.c:453) reads rid, rb and re, which
+	// nothing here changes: it is evaluated 64 entries at a time, and lane 0 then visits the entries that passed
+	for (int cbase = 0; cbase < n; cbase += 64) {
+		const int ii = cbase + l;
+		unsigned long long act_m = __ballot(ii >= 1 && ii < n && L[ii].rid == L[ii - 1].rid && L[ii].rb < L[ii - 1].re + o.max_chain_gap);
+		if (l == 0) while (act_m) {
+			const int i = cbase + __ffsll((long long)act_m) - 1;
+			act_m &= act_m - 1;
 			DevReg *p = &L[i];
-			if (p->rid != L[i-1].rid || p->rb >= L[i-1].re + o.max_chain_gap) continue;
 			for (int j = i - 1; j >= 0 && p->rid == L[j].rid && p->rb < L[j].re + o.max_chain_gap; --j) {
 				DevReg *q = &L[j];
 				if (q->qe == q->qb) continue;
@@ -227,7 +235,8 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 	n = m;
 	for (int i = l; i < n; i += 64) { L[i] = tmp[i]; keys[i].k64 = tmp[i].rb; keys[i].score = tmp[i].score; keys[i].qb = tmp[i].qb; idx[i] = i; }
 	wsync();
-	if (n < 8 || !wave_rank_sort(RegSort{keys, 1}, n, idx, l)) {
+	if (!wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(tmp), stk, lds256, l)) {
+		wsync();
 		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, stk, &bad); if (bad) atomicExch(err, 50 + bad); }
 	}
 	wsync();
@@ -339,7 +348,7 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 			}
 			++n;
 		}
-		if (n) { const unsigned long long tk3 = wall_clock64(); n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, l, a.err); if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }
+		if (n) { const unsigned long long tk3 = wall_clock64(); n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, reinterpret_cast<unsigned*>(m.h), l, a.err); if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }
 	}
 	return n_ma;
 }

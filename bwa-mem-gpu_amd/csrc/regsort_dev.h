@@ -2,6 +2,7 @@
 // mem_sort_dedup_patch as mem_matesw calls it): ks_introsort on mem_ars2 / mem_ars (bwamem.c:398-402, ksort.h:176-227).
 #pragma once
 #include "bwahip_internal.h"
+#include "isort_dev.h"
 
 namespace wv {
 
@@ -44,6 +45,55 @@ __device__ __forceinline__ bool wave_rank_sort(const RegSort c, int n, int *idx,
 	}
 	__threadfence_block(); __syncthreads();
 	for (int i = l; i < n; i += 64) idx[i] = idx[n + i];
+	return true;
+}
+
+// ks_introsort(mem_ars2 / mem_ars) on idx[0..n) (identity on entry) by the whole wavefront, exact for any input: keys without ties are
+// placed by rank; with ties the quicksort phase of the reference's introsort is followed in parallel (isort_dev.h).
+//   work: 8-byte aligned global scratch of ws_work_ints(n) ints; stk: 240 ints (LDS); lds: 256 words of LDS.
+// false (idx untouched): the introsort's depth limit was reached or n > 65535 -- the caller runs rs_introsort on one lane.
+__device__ __forceinline__ size_t ws_work_ints(int n) { return is_scratch_ints(n) + (size_t)n + (size_t)n / 4 + 4; }
+__device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int *stk, unsigned *lds, int l)
+{
+	if (n > 65535) return false;
+	int *qs_scratch = work;
+	unsigned *v = reinterpret_cast<unsigned*>(work + is_scratch_ints(n));
+	uint8_t *tied = reinterpret_cast<uint8_t*>(v + n);
+	RegKey *tile = reinterpret_cast<RegKey*>(lds);               // 64 keys of 16 bytes
+	unsigned long long any_tie = 0;
+	for (int base = 0; base < n; base += 64) {
+		const int t = base + l;
+		RegKey kt; kt.k64 = 0; kt.score = 0; kt.qb = 0;
+		if (t < n) kt = c.key[t];
+		int cnt = 0; bool tie = false;
+		for (int ub = 0; ub < n; ub += 64) {
+			is_sync();
+			if (ub + l < n) tile[l] = c.key[ub + l];
+			is_sync();
+			const int hi = n - ub < 64 ? n - ub : 64;
+			for (int u = 0; u < hi; ++u) {
+				const RegKey ku = tile[u];
+				bool lt_ut, eq;
+				if (c.mode == 0) { lt_ut = ku.k64 < kt.k64; eq = ku.k64 == kt.k64; }
+				else {
+					eq = ku.score == kt.score && ku.k64 == kt.k64 && ku.qb == kt.qb;
+					lt_ut = ku.score > kt.score || (ku.score == kt.score && (ku.k64 < kt.k64 || (ku.k64 == kt.k64 && ku.qb < kt.qb)));
+				}
+				cnt += lt_ut ? 1 : 0;
+				tie |= eq && ub + u != t;
+			}
+		}
+		if (t < n) { v[t] = (unsigned)cnt << 16 | (unsigned)t; tied[t] = tie ? 1 : 0; }
+		any_tie |= __ballot(t < n && tie);
+	}
+	is_sync();
+	if (!any_tie) {
+		for (int t = l; t < n; t += 64) idx[v[t] >> 16] = t;
+		is_sync();
+		return true;
+	}
+	if (!wave_qs_phase(v, n, qs_scratch, stk, lds, l)) return false;
+	wave_final_place(v, n, tied, idx, l);
 	return true;
 }
 

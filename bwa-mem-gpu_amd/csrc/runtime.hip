@@ -306,7 +306,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t,
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t, &c->d_dedup,
 	                   &c->d_ctg_names, &c->d_ctg_name_off, &c->d_ctg_anno, &c->d_ctg_anno_off, &c->d_rg, &c->d_qual, &c->d_qual_off, &c->d_names, &c->d_name_off, &c->d_comments, &c->d_comment_off,
 	                   &c->d_fregs, &c->d_fregs2, &c->d_fscr, &c->d_need, &c->d_xa_owner, &c->d_freg_n, &c->d_npri, &c->d_task_n, &c->d_rec_n, &c->d_task_base, &c->d_tasks, &c->d_aln_of_reg, &c->d_alns,
 	                   &c->d_resc_flag, &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
@@ -386,6 +386,28 @@ int bwahip_kat_ksw_align(bwahip_ctx *c, int n, const int *params, const int8_t *
 	if (!rc && hipMemcpy(out7, dout.p, (size_t)n * 28, hipMemcpyDeviceToHost) != hipSuccess) rc = BWAHIP_ENODEV;
 done:
 	dp.release(); dq.release(); dqo.release(); dt.release(); dto.release(); dout.release(); dit.release(); dw.release();
+	return rc;
+}
+
+// The region-list sorts (ks_introsort on mem_ars2 / mem_ars keys, bwamem.c:398-402) as the kernels run them: the wavefront's exact form and
+// the one-lane restatement on the same n keys {k64, score, qb} (mode 0: by k64; mode 1: score desc, k64, qb).  idx_par / idx_seq: the two
+// permutations (n ints each); status2[0] = 1 when the parallel form ran to the end (0: it fell back, idx_par is the identity), status2[1] != 0: error.
+int bwahip_kat_introsort(bwahip_ctx *c, int n, int mode, const int64_t *k64, const int *score, const int *qb, int *idx_par, int *idx_seq, int *status2)
+{
+	if (!c || n < 1 || n > 65535 || (mode != 0 && mode != 1) || !k64 || !score || !qb || !idx_par || !idx_seq || !status2) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	struct K16 { int64_t k64; int score, qb; };
+	std::vector<K16> keys(n);
+	for (int i = 0; i < n; ++i) keys[i] = { k64[i], score[i], qb[i] };
+	DevBuf dk, dp, ds, dw, dst; int rc;
+	if ((rc = upload(dk, keys.data(), (size_t)n * 16, c->stream)) || (rc = dp.ensure((size_t)n * 8)) || (rc = ds.ensure((size_t)n * 8)) ||
+	    (rc = dw.ensure(kat_isort_work_ints(n) * 4 + 64)) || (rc = dst.ensure(16))) goto done;
+	rc = launch_kat_isort(n, mode, dk.p, dp.as<int>(), ds.as<int>(), dw.as<int>(), dst.as<int>(), c->stream);
+	if (!rc && (hipMemcpyAsync(idx_par, dp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(idx_seq, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+	            hipMemcpyAsync(status2, dst.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) rc = BWAHIP_ENODEV;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+done:
+	dk.release(); dp.release(); ds.release(); dw.release(); dst.release();
 	return rc;
 }
 
@@ -616,6 +638,9 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		el.counters = counters; el.err = err;
 		if ((rc = c->d_redo.ensure((size_t)(n + 4) * 4)) || (rc = c->d_big_t.ensure((size_t)BWAHIP_EXT_BIG_GRID * (BWAHIP_EXT_BIG_T + 64)))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 16, c->stream));
+		if ((rc = c->d_dedup.ensure((size_t)(n + 4) * 4))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_dedup.p, 0, 16, c->stream));
+		el.dedup_n = c->d_dedup.as<int>(); el.dedup_list = c->d_dedup.as<int>() + 4;
 		el.redo_n = c->d_redo.as<int>(); el.redo_list = c->d_redo.as<int>() + 4; el.big_t = c->d_big_t.as<uint8_t>(); el.lds_window = c->knobs.ext_lds_window;
 		el.rank_sort_min = c->knobs.rank_sort_min;
 		const int spec_min = c->knobs.spec_min_chains;           // 0 = no ahead-of-time extension

@@ -322,6 +322,12 @@ int bwahip_kat_extend(bwahip_ctx *ctx, int n, const uint64_t *ik3, const int *is
 int bwahip_kat_ksw_extend(bwahip_ctx *ctx, int n, const int *params /*n x 10*/, const uint8_t *q, const int64_t *qoff,
                           const uint8_t *t, const int64_t *toff, int *out6 /*n x 6*/);
 
+/* The region-list sorts (ks_introsort over mem_ars2 / mem_ars keys, bwamem.c:398-402, ksort.h:176) as the kernels run them: the whole
+ * wavefront's exact form (csrc/isort_dev.h) and the one-lane restatement of ksort.h on the same n keys {k64, score, qb} (mode 0: by k64;
+ * mode 1: score descending, k64, qb).  idx_par / idx_seq: the two permutations; status2[0] = 1 when the parallel form ran to the end
+ * (0: the introsort's depth limit -- it hands over to the one-lane form, idx_par is the identity), status2[1] != 0: internal error. */
+int bwahip_kat_introsort(bwahip_ctx *ctx, int n, int mode, const int64_t *k64, const int *score, const int *qb, int *idx_par, int *idx_seq, int *status2);
+
 /* ksw_align2 (ksw.c:343) on the device, byte or word kernel as xtra's KSW_XBYTE says.  params: n x 8 ints
  * (qlen, tlen, xtra, o_del, e_del, o_ins, e_ins, 0); mat25 NULL = the default 1/-4 matrix; out7: n x 7
  * (score, te, qe, score2, te2, tb, qb). */

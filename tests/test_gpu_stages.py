@@ -16,7 +16,7 @@ def ctx(small_index):
     c.close()
 
 
-KNOB_DEFAULTS = dict(intv_cap=96, smem_lanes=1, heavy_mult=10, chain_big_min=512, rank_sort_min=192, spec_min_chains=16, ext_lds_window=1 << 30)
+KNOB_DEFAULTS = dict(intv_cap=96, smem_lanes=1, heavy_mult=10, chain_big_min=512, rank_sort_min=2, spec_min_chains=16, ext_lds_window=1 << 30)
 
 
 @pytest.fixture
@@ -358,6 +358,44 @@ def _genome_slice(small_index, start, length):
             seq.append(line.strip())
     g = b"".join(seq)
     return g[start:start + length]
+
+
+def test_wavefront_introsort_equals_ksort_restatement(ctx):
+    """The region-list sorts are the reference's UNSTABLE ks_introsort (ksort.h:176): with equal keys the resulting order is a property of that
+    algorithm.  The kernels run it on the whole wavefront (csrc/isort_dev.h: parallel partition steps + stable final placement); here its
+    permutation must equal the one-lane restatement's on keys with no, few and many ties, in both key modes, and must be a sorted order."""
+    rng = np.random.default_rng(77)
+    n_par = 0
+    for trial in range(160):
+        n = int(rng.choice([1, 2, 3, 5, 16, 17, 18, 33, 63, 64, 65, 100, 129, 257, 700, 1500, 4000]))
+        mode = trial & 1
+        kind = trial % 5
+        if kind == 0:                                            # no ties
+            k64 = rng.permutation(n).astype(np.int64) * 7919
+            score = rng.integers(20, 150, n).astype(np.int32); qb = rng.integers(0, 100, n).astype(np.int32)
+        elif kind == 1:                                          # a few duplicates (a rescued hit that repeats one of the list)
+            k64 = rng.permutation(n).astype(np.int64) * 13
+            score = rng.integers(20, 150, n).astype(np.int32); qb = rng.integers(0, 100, n).astype(np.int32)
+            for _ in range(max(1, n // 20)):
+                i, j = rng.integers(0, n, 2)
+                k64[i], score[i], qb[i] = k64[j], score[j], qb[j]
+        elif kind == 2:                                          # many ties
+            k64 = rng.integers(0, max(1, n // 4), n).astype(np.int64)
+            score = rng.integers(0, 3, n).astype(np.int32); qb = rng.integers(0, 2, n).astype(np.int32)
+        elif kind == 3:                                          # three distinct keys
+            k64 = rng.integers(0, 3, n).astype(np.int64); score = np.zeros(n, np.int32); qb = np.zeros(n, np.int32)
+        else:                                                    # sorted input with ties (the reference's introsort reaches its depth limit here)
+            k64 = np.sort(rng.integers(0, max(1, n // 2), n)).astype(np.int64); score = np.full(n, 60, np.int32); qb = np.zeros(n, np.int32)
+        par, seq, ran = ctx.kat_introsort(k64, score, qb, mode)
+        assert sorted(seq.tolist()) == list(range(n))
+        key = (lambda i: (int(k64[i]),)) if mode == 0 else (lambda i: (-int(score[i]), int(k64[i]), int(qb[i])))
+        assert all(key(seq[i]) <= key(seq[i + 1]) for i in range(n - 1)), "the restatement did not sort"
+        if ran:
+            n_par += 1
+            assert np.array_equal(par, seq), f"trial {trial}: n {n} mode {mode} kind {kind}"
+        else:
+            assert kind == 4 or n > 1000, f"unexpected hand-over: n {n} kind {kind}"   # only the depth limit hands over
+    assert n_par >= 100
 
 
 def test_edge_cases_ragged_batch(ctx, small_index, tmp_path):
