@@ -14,6 +14,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../../include/bwamem_hip.h"
 
 static struct { const void *bwt, *bns, *pac; bwahip_ctx *ctx; int atexit_set; } g_cache;
@@ -31,11 +32,17 @@ static void compat_fatal(const char *what, int rc)
 }
 
 /* Read group id (the reference's global bwa_rg_id, bwa.c:44): a caller that honours -R forwards it here. */
-static const char *g_rg_id = "";
-void bwahip_compat_set_rg_id(const char *id) { g_rg_id = id ? id : ""; if (g_cache.ctx) bwahip_ctx_set_rg_id(g_cache.ctx, g_rg_id); }
+static char *g_rg_id = 0;                                  /* own copy: the caller's buffer (bwa_rg_id, bwa.c:44) may be reused */
+void bwahip_compat_set_rg_id(const char *id)
+{
+	char *copy = id && *id ? strdup(id) : 0;
+	free(g_rg_id);
+	g_rg_id = copy;
+	if (g_cache.ctx) bwahip_ctx_set_rg_id(g_cache.ctx, g_rg_id ? g_rg_id : "");
+}
 
 /* Drop the cached context (e.g. before unloading the index). */
-void bwahip_compat_release(void) { compat_release(); }
+void bwahip_compat_release(void) { compat_release(); free(g_rg_id); g_rg_id = 0; }
 
 void mem_process_seqs(const bwahip_opt_t *opt, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t *pac,
                       int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
@@ -47,7 +54,7 @@ void mem_process_seqs(const bwahip_opt_t *opt, const bwahip_bwt_t *bwt, const bw
 		rc = bwahip_init(bwt, bns, pac, dev ? atoi(dev) : 0, &g_cache.ctx);
 		if (rc) compat_fatal("bwahip_init", rc);
 		g_cache.bwt = bwt; g_cache.bns = bns; g_cache.pac = pac;
-		bwahip_ctx_set_rg_id(g_cache.ctx, g_rg_id);
+		bwahip_ctx_set_rg_id(g_cache.ctx, g_rg_id ? g_rg_id : "");
 		if (!g_cache.atexit_set) { atexit(compat_release); g_cache.atexit_set = 1; }
 	}
 	rc = bwahip_process_seqs(g_cache.ctx, opt, n_processed, n, seqs, pes0);

@@ -8,7 +8,28 @@
 #include <algorithm>
 #include <chrono>
 
-int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);   // host_final.cpp
+#include <dlfcn.h>
+// The host finalisation is test infrastructure (csrc/host_final.cpp, built as libbwahip_hostfinal.so beside this library) and not linked
+// in: the knobs gpu_final = 0 / gpu_pair = 0 load it on demand.  Without it those knobs are an error -- there is no CPU path in the product.
+typedef int (*host_final_fn)(bwahip_ctx*, const bwahip_opt_t*, int64_t, int, bwahip_seq_t*, const bwahip_pestat_t*);
+static host_final_fn load_host_final()
+{
+	static host_final_fn fn = nullptr;
+	static bool tried = false;
+	if (tried) return fn;
+	tried = true;
+	Dl_info di;
+	std::string path = "libbwahip_hostfinal.so";
+	if (dladdr((const void*)&bwahip_version, &di) && di.dli_fname) {
+		const std::string self = di.dli_fname;
+		const size_t sl = self.rfind('/');
+		if (sl != std::string::npos) path = self.substr(0, sl + 1) + path;
+	}
+	void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+	if (h) fn = (host_final_fn)dlsym(h, "bwahip_process_seqs_host");
+	if (!fn) fprintf(stderr, "[bwahip] gpu_final / gpu_pair = 0 need the test library %s (%s)\n", path.c_str(), h ? "symbol missing" : dlerror());
+	return fn;
+}
 
 // contig names and annotations as flat byte tables (RNAME, SA / XA entries, XR)
 int final_setup(bwahip_ctx *c)
@@ -217,7 +238,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 			if ((rc = launch_pair(pl, n_resc, c->stream))) return rc;
 		}
 		f.subset = 0; pl.subset = 0;
-		HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 24, hipMemcpyDeviceToHost, c->stream));   // [0..2]; [3] = pairs rescued is the host's
+		HIP_TRY(hipMemcpyAsync(c->last_pe_counters, pl.counters, 72, hipMemcpyDeviceToHost, c->stream));   // [0..3] as documented; [4..8]: ticks of 10 ns in the window fetch, the alignments and the list clean-up of k_matesw, its longest pair, alignments it ran itself
 		f.pe_read = pl.pe_read;
 		memcpy(f.pes, pl.pes, sizeof f.pes);
 	}
@@ -440,7 +461,8 @@ static int process_seqs_impl(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n
 	if (text_out) { *text_out = ""; *len_out = 0; if (off_out) *off_out = nullptr; }
 	if (!ctx->knobs.gpu_final || (pe && !ctx->knobs.gpu_pair)) {
 		if (text_out) return BWAHIP_EINVAL;                       // the one-piece output exists on the GPU path only
-		return bwahip_process_seqs_host(ctx, opt, n_processed, n, seqs, pes0);
+		host_final_fn hf = load_host_final();
+		return hf ? hf(ctx, opt, n_processed, n, seqs, pes0) : BWAHIP_EINVAL;
 	}
 	if (pe) for (int i = 0; i < n; i += 2) if (strcmp(seqs[i].name, seqs[i + 1].name) != 0) { fprintf(stderr, "[bwahip] paired reads have different names\n"); return BWAHIP_EINVAL; }   // err_fatal in the reference (bwamem_pair.c:386)
 	if (n == 0) return 0;
@@ -555,5 +577,10 @@ extern "C" int bwahip_last_pe_stats(bwahip_ctx *ctx, bwahip_pestat_t *pes4, uint
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	if (pes4) memcpy(pes4, ctx->last_pes, sizeof ctx->last_pes);
 	if (counters2) for (int i = 0; i < 4; ++i) counters2[i] = ctx->last_pe_counters[i];
+	if (getenv("BWAHIP_PE_LOG")) {
+		const unsigned long long *c = ctx->last_pe_counters;
+		fprintf(stderr, "[bwahip] mate rescue: %llu alignments (%llu inside k_matesw), %llu regions added, %llu pairs; k_matesw summed over its wavefronts: window fetch %.1f ms, alignments %.1f ms, list clean-up %.1f ms; longest pair %.2f ms\n",
+		        c[0], c[8], c[1], c[3], c[4] / 1e5, c[5] / 1e5, c[6] / 1e5, c[7] / 1e5);
+	}
 	return 0;
 }

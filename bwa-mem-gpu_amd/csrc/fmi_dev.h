@@ -200,7 +200,7 @@ __device__ __forceinline__ void lane_occ4_pair(const DevIndex &ix, uint64_t pk, 
 	const bool k_hi = (kk & 127) >= 64, l_hi = (ll & 127) >= 64;
 	if (live && !nk) { const uint4 *b = ix.bwt + (kk >> 7) * 4; a0 = b[0]; a1 = b[1]; a2 = b[2]; if (k_hi || (same && l_hi)) a3 = b[3]; }
 	uint4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
-	if (live && !same) { const uint4 *b = ix.bwt + (ll >> 7) * 4; b0 = b[0]; b1 = b[1]; b2 = b[2]; if (l_hi) b3 = b[3]; }
+	if (live && !same && pl != ~0ull) { const uint4 *b = ix.bwt + (ll >> 7) * 4; b0 = b[0]; b1 = b[1]; b2 = b[2]; if (l_hi) b3 = b[3]; }   // (l = -1: the counts are zeroed below, nothing to fetch)
 	{
 		const int o = (int)(kk & 127) + 1;
 		const uint32_t packed = count_bases64(a2, o < 64 ? o : 64) + count_bases64(a3, o > 64 ? o - 64 : 0);

@@ -1,8 +1,9 @@
-// Host side of bwahip_process_seqs: everything mem_process_seqs does AFTER the hot path (worker2, bwamem.c:1197):
-// mark primary / mapQ / CIGAR+NM+MD / SAM text for single-end reads, and for pairs insert-size statistics,
-// mate rescue, pairing and paired SAM output.  The hot path (mem_align1_core) itself runs on the GPU
-// (bwahip_align_batch); nothing in this file can substitute for it.  SURVEY.md section 8(f) ranks moving
-// this finalisation to the GPU as the next step; until then it runs on opt->n_threads host threads.
+// TEST INFRASTRUCTURE, not part of libbwahip.so: a second, independent implementation of everything mem_process_seqs does AFTER the hot
+// path (worker2, bwamem.c:1197) -- mark primary / mapQ / CIGAR+NM+MD / SAM text for single-end reads, and for pairs insert-size
+// statistics, mate rescue, pairing and paired SAM output -- on host threads, on top of the library's public C ABI (bwahip_align_batch
+// gives it the regions the GPU hot path found).  It is built as libbwahip_hostfinal.so; the product's finalisation are the GPU kernels of
+// k_final.hip / k_pair.hip / k_sam.hip, which the tests cross-check against this one (knobs gpu_final = 0 / gpu_pair = 0 make
+// bwahip_process_seqs load it).  Round 1's product path; kept because two implementations that agree byte for byte pin each other.
 //
 // Reference semantics restated here (file:line in /root/reference):
 //   bwamem.c:500-565 mark primary      bwamem.c:962-986 mapQ          bwamem.c:988-1010 primary5 reorder
@@ -1027,8 +1028,8 @@ static int sam_pe(const Opt &o, const Ref &ref, const PeStat pes[4], uint64_t id
 } // namespace hf
 
 // ================================================================ C ABI: bwahip_process_seqs == mem_process_seqs (bwamem.c:1215)
-// Host finalisation after the GPU hot path: paired-end batches (until mem_sam_pe moves to the GPU) and the gpu_final = 0 knob.
-int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
+// Host finalisation after the GPU hot path (the gpu_final = 0 / gpu_pair = 0 knobs of the tests).
+extern "C" int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0)
 {
 	if (!ctx || !opt || n < 0 || (n && !seqs)) return BWAHIP_EINVAL;
 	const bool pe = (opt->flag & BWAHIP_F_PE) != 0;
@@ -1082,19 +1083,3 @@ int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n
 	return 0;
 }
 
-// Concatenate the SAM text of seqs[0..n) into one malloc()ed buffer (read order) and free the per-read strings: what a
-// caller that writes the batch's SAM with one fwrite wants (the reference's output step, fastmap.c, fputs per read).
-extern "C" int bwahip_seqs_take_sam(bwahip_seq_t *seqs, int n, char **out, int64_t *out_len)
-{
-	if (n < 0 || (n && !seqs) || !out || !out_len) return BWAHIP_EINVAL;
-	std::vector<size_t> off((size_t)n + 1, 0);
-	for (int i = 0; i < n; ++i) off[i + 1] = off[i] + (seqs[i].sam ? strlen(seqs[i].sam) : 0);
-	char *buf = (char*)malloc(off[n] + 1);
-	if (!buf) return BWAHIP_ENOMEM;
-	par_for_chunks(n, 16, [&](int64_t b, int64_t e) {
-		for (int64_t i = b; i < e; ++i) if (seqs[i].sam) { memcpy(buf + off[i], seqs[i].sam, off[i + 1] - off[i]); free(seqs[i].sam); seqs[i].sam = nullptr; }
-	});
-	buf[off[n]] = 0;
-	*out = buf; *out_len = (int64_t)off[n];
-	return 0;
-}

@@ -159,3 +159,25 @@ void bwahip_free_host_index(HostIndex *h)
 	free(h->bns.anns); free(h->bns.ambs); free(h->pac);
 	memset(h, 0, sizeof(*h));
 }
+
+// Concatenate the SAM text of seqs[0..n) into one malloc()ed buffer (read order) and free the per-read strings: what a
+// caller that writes the batch's SAM with one fwrite wants (the reference's output step, fastmap.c, fputs per read).
+extern "C" int bwahip_seqs_take_sam(bwahip_seq_t *seqs, int n, char **out, int64_t *out_len)
+{
+	if (n < 0 || (n && !seqs) || !out || !out_len) return BWAHIP_EINVAL;
+	std::vector<size_t> off((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) off[i + 1] = off[i] + (seqs[i].sam ? strlen(seqs[i].sam) : 0);
+	char *buf = (char*)malloc(off[n] + 1);
+	if (!buf) return BWAHIP_ENOMEM;
+	{
+		const int nt = n >= 4096 ? 16 : 1;
+		std::vector<std::thread> th;
+		auto work = [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) if (seqs[i].sam) { memcpy(buf + off[i], seqs[i].sam, off[i + 1] - off[i]); free(seqs[i].sam); seqs[i].sam = nullptr; } };
+		for (int k = 1; k < nt; ++k) th.emplace_back(work, (int64_t)n * k / nt, (int64_t)n * (k + 1) / nt);
+		work(0, (int64_t)n / nt);
+		for (auto &x : th) x.join();
+	}
+	buf[off[n]] = 0;
+	*out = buf; *out_len = (int64_t)off[n];
+	return 0;
+}

@@ -184,20 +184,29 @@ __device__ bool wave_qs_phase(unsigned *v, int n, int *scratch, int *stk, unsign
 	}
 }
 
-// The final insertion sort as a stable placement: element at position p of v goes to slot (its count of smaller keys) + (equal keys at
-// positions before p).  tied[e] != 0: element e shares its key with another one (only those need the second count).  idx_out[slot] = element.
-__device__ void wave_final_place(const unsigned *v, int n, const uint8_t *tied, int *idx_out, int l)
+// The final insertion sort as a stable placement: the element at position p of v goes to slot (its count of smaller keys) + (equal keys at
+// positions before p) = the number of packed words (count << 16 | position) below its own.  tied[e] != 0: element e shares its key with
+// another one (only those need the count; the others' slot is their count of smaller keys).  idx_out[slot] = element.  tile: 256 words of LDS.
+__device__ void wave_final_place(const unsigned *v, int n, const uint8_t *tied, int *idx_out, unsigned *tile, int l)
 {
 	for (int base = 0; base < n; base += 64) {
 		const int p = base + l;
 		const unsigned val = p < n ? v[p] : 0u;
 		const bool need = p < n && tied[val & 0xffffu];
-		int before = 0;
+		const unsigned mine = (val & 0xffff0000u) | (unsigned)p;
+		int slot = (int)(val >> 16);
 		if (__ballot(need)) {
-			const int hi = base + 64 < n ? base + 64 : n;
-			for (int q = 0; q < hi; ++q) { const unsigned o = v[q]; before += (need && q < p && (o >> 16) == (val >> 16)) ? 1 : 0; }
+			slot = 0;
+			for (int qb = 0; qb < n; qb += 256) {
+				is_sync();
+				for (int q = qb + l; q < qb + 256 && q < n; q += 64) tile[q - qb] = (v[q] & 0xffff0000u) | (unsigned)q;
+				is_sync();
+				const int hi = n - qb < 256 ? n - qb : 256;
+				for (int q = 0; q < hi; ++q) slot += tile[q] < mine ? 1 : 0;
+			}
+			if (!need) slot = (int)(val >> 16);
 		}
-		if (p < n) idx_out[(int)(val >> 16) + before] = (int)(val & 0xffffu);
+		if (p < n) idx_out[slot] = (int)(val & 0xffffu);
 	}
 	is_sync();
 }

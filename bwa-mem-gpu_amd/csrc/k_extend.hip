@@ -630,7 +630,7 @@ constexpr int BIG_T = BWAHIP_EXT_BIG_T;
 // PHASE 0: both parts (k_extend_big); 1: the mem_chain2aln calls only -- a read left with more than one region is listed for k_dedup (its
 // sorts and the dedup pass want other registers and run as their own launch); 2: mem_sort_dedup_patch of a listed read.
 template <int CPL, bool BIGT, int PHASE>
-__device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uint8_t *s_q, uint8_t *s_t, int8_t *s_mat, int *s_stk, unsigned *s_he)
+__device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uint8_t *s_q, uint8_t *s_t, int8_t *s_mat, int *s_stk, unsigned *s_he, unsigned *s_v = nullptr, int v_cap = 0)
 {
 	const int T_CAP = BIGT ? BIG_T : (a.lds_window < MAXT ? a.lds_window : MAXT);   // lds_window: test knob, forces the hand-over onto ordinary reads
 	const int l = lane();
@@ -783,7 +783,7 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 		__threadfence_block(); __syncthreads();
 		// ks_introsort(mem_ars2): by the whole wavefront, exact also with equal keys (regsort_dev.h / isort_dev.h); the one-lane restatement
 		// only when the introsort's depth limit is reached (or the test knob asks for it).  Scratch: behind the keys in the spare list.
-		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l)) {
+		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l, s_v, v_cap)) {
 			__threadfence_block(); __syncthreads();
 			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
 		}
@@ -928,7 +928,7 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 		}
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].rb; keys[i].score = av[i].score; keys[i].qb = av[i].qb; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l)) {
+		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l, s_v, v_cap)) {
 			__threadfence_block(); __syncthreads();
 			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad); }
 		}
@@ -987,9 +987,10 @@ __global__ __launch_bounds__(64) void k_dedup(ExtLaunch a)
 	__shared__ int8_t s_mat[32];
 	__shared__ int s_stk[3 * 80];
 	__shared__ unsigned s_he[WIN_MAX];
+	__shared__ unsigned s_v[2048];                              // the sort's working array for lists up to 2048 regions (longer ones: global memory)
 	const int n_list = *a.dedup_n;
 	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
-		extend_read<CPL, false, 2>(a, a.dedup_list[it], s_q, s_t, s_mat, s_stk, s_he);
+		extend_read<CPL, false, 2>(a, a.dedup_list[n_list - 1 - it], s_q, s_t, s_mat, s_stk, s_he, s_v, 2048);   // from the end of the list: the reads k_extend finished last are the ones with the longest lists
 		__syncthreads();
 	}
 }
@@ -1010,14 +1011,36 @@ __global__ __launch_bounds__(64) void k_extend_big(ExtLaunch a)
 	}
 }
 
-// Scheduling aid: reads with many seeds to extend go to the front of the launch order so that the long
-// ones start first and the short ones fill in behind them (the order has no effect on results).
-__global__ void k_order(int n, const int *kept_seeds, int *perm, int *counts)
+// Scheduling aid: reads with many seeds to extend go to the front of the launch order, the heaviest first, so that the long ones
+// start at once and the short ones fill in behind them (the order has no effect on results).  Four classes by the number of seeds
+// left after chain filtering; counts[0..3]: class sizes, counts[4..7]: cursors.
+__device__ __forceinline__ int order_class(int kept) { return kept >= 1024 ? 0 : kept >= 256 ? 1 : kept >= 64 ? 2 : 3; }
+__global__ void k_order_count(int n, const int *kept_seeds, int *counts)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n) return;
-	if (kept_seeds[r] >= 64) perm[atomicAdd(&counts[0], 1)] = r;
-	else perm[n - 1 - atomicAdd(&counts[1], 1)] = r;
+	const int c = r < n ? order_class(kept_seeds[r]) : 3;
+	// one atomic per class and wavefront
+	for (int k = 0; k < 4; ++k) {
+		const unsigned long long m = __ballot(r < n && c == k);
+		if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&counts[k], __popcll(m));
+	}
+}
+__global__ void k_order_place(int n, const int *kept_seeds, int *perm, int *counts)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	const int c = r < n ? order_class(kept_seeds[r]) : 3;
+	const int l = threadIdx.x & 63;
+	for (int k = 0; k < 4; ++k) {
+		const unsigned long long m = __ballot(r < n && c == k);
+		if (!m) continue;
+		int base = 0;
+		const int lead = __ffsll((long long)m) - 1;
+		if (l == lead) base = atomicAdd(&counts[4 + k], __popcll(m));
+		base = __shfl(base, lead);
+		int start = 0;
+		for (int j = 0; j < k; ++j) start += counts[j];
+		if (r < n && c == k) perm[start + base + __popcll(m & ((1ull << l) - 1))] = r;
+	}
 }
 
 // known-answer kernel: ksw_extend2 on caller-supplied pairs (params per item: qlen,tlen,w,h0,zdrop,end_bonus,o_del,e_del,o_ins,e_ins)
@@ -1095,8 +1118,9 @@ int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 {
 	if (a.n_reads <= 0) return 0;
 	if (a.perm) {
-		(void)hipMemsetAsync(a.perm_counts, 0, 8, st);
-		hipLaunchKernelGGL(k_order, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.kept_seeds, a.perm, a.perm_counts);
+		(void)hipMemsetAsync(a.perm_counts, 0, 32, st);
+		hipLaunchKernelGGL(k_order_count, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.kept_seeds, a.perm_counts);
+		hipLaunchKernelGGL(k_order_place, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.kept_seeds, a.perm, a.perm_counts);
 	}
 	// columns 0..max_len must fit in 64 lanes x CPL registers
 	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend<3>, dim3(a.n_reads), dim3(64), 0, st, a);

@@ -597,31 +597,53 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			else if (CPLMAX <= 4 || lq < 256) score = wave_global_trace<(CPLMAX < 4 ? CPLMAX : 4)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			else score = wave_global_trace<CPLMAX>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			wsync();
-			// ---- backtrack (ksw.c:586-603); operations are produced last to first and reversed afterwards
+			// ---- backtrack (ksw.c:586-603); operations are produced last to first and reversed afterwards.  The walk is a chain of dependent
+			// reads of z, but nearly all of its steps are diagonal ones in state 0 (match / mismatch): there the next cells are known in
+			// advance -- (i - t, k - t) -- so 64 of them are read at once, one per lane, and a ballot finds the first that leaves the
+			// diagonal.  Gap states (1: deletion, 2: insertion) are followed cell by cell.  Same cells, same decisions, same operations.
 			int nc = 0;
-			if (l == 0) {
+			{
 				int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
 				uint32_t cur = 0; bool have = false, ovf = false;
-				auto push = [&](int op, int len) {
+				auto push = [&](int op, int len) {                    // uniform over the wavefront; lane 0 stores
 					if (have && (int)(cur & 0xf) == op) cur += (uint32_t)len << 4;
-					else { if (have) { if (nc < m.max_c) m.cig[nc] = cur; else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
+					else { if (have) { if (nc < m.max_c) { if (l == 0) m.cig[nc] = cur; } else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
+				};
+				auto cell = [&](int ii, int kk) -> int {              // the z byte of ksw.c:551-572 for cell (row ii, column kk)
+					if (nib_z || nib2_z) {
+						const int kd = kk - ii + w;
+						const int byte = nib_z ? m.z[(size_t)(ii >> 1) * (2 * w + 1) + kd] : m.z[(size_t)ii * (w + 1) + (kd >> 1)];
+						const int nb = (nib_z ? (ii & 1) : (kd & 1)) ? byte >> 4 : byte & 15;
+						return (nb & 3) | (nb >> 2 & 1) << 2 | (nb >> 3 & 1) << 5;
+					}
+					return m.z[(size_t)ii * n_col + (kk - (ii > w ? ii - w : 0))];
 				};
 				while (i >= 0 && k >= 0) {
-					if (nib_z || nib2_z) {
-						const int kd = k - i + w;
-						const int byte = nib_z ? m.z[(size_t)(i >> 1) * (2 * w + 1) + kd] : m.z[(size_t)i * (w + 1) + (kd >> 1)];
-						const int nb = (nib_z ? (i & 1) : (kd & 1)) ? byte >> 4 : byte & 15;
-						which = which == 0 ? (nb & 3) : which == 1 ? (nb >> 2 & 1) : (nb >> 3 & 1) << 1;
-					} else which = m.z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-					if (which == 0) { push(0, 1); --i; --k; }
-					else if (which == 1) { push(2, 1); --i; }
-					else { push(1, 1); --k; }
+					if (which == 0) {
+						const int ii = i - l, kk = k - l;
+						const bool valid = ii >= 0 && kk >= 0;
+						const int d = valid ? cell(ii, kk) : 0;
+						const unsigned long long stop = __ballot(!valid || (d & 3) != 0);
+						const int run = stop ? __ffsll((long long)stop) - 1 : 64;
+						if (run > 0) { push(0, run); i -= run; k -= run; }
+						if (stop) {
+							const int dr = __shfl(valid ? d : 0, run);        // 0: the matrix ended there (i or k is negative now)
+							which = dr & 3;
+							if (which == 1) { push(2, 1); --i; } else if (which == 2) { push(1, 1); --k; }
+						}
+					} else {
+						which = cell(i, k) >> (which << 1) & 3;
+						if (which == 0) { push(0, 1); --i; --k; }
+						else if (which == 1) { push(2, 1); --i; }
+						else { push(1, 1); --k; }
+					}
 				}
 				if (i >= 0) push(2, i + 1);
 				if (k >= 0) push(1, k + 1);
-				if (have) { if (nc < m.max_c) m.cig[nc] = cur; else ovf = true; ++nc; }
+				if (have) { if (nc < m.max_c) { if (l == 0) m.cig[nc] = cur; } else ovf = true; ++nc; }
+				wsync();
 				if (ovf) nc = -1;
-				else for (int x = 0; x < nc >> 1; ++x) { const uint32_t tmp = m.cig[x]; m.cig[x] = m.cig[nc - 1 - x]; m.cig[nc - 1 - x] = tmp; }
+				else if (l == 0) for (int x = 0; x < nc >> 1; ++x) { const uint32_t tmp = m.cig[x]; m.cig[x] = m.cig[nc - 1 - x]; m.cig[nc - 1 - x] = tmp; }
 			}
 			nc = __shfl(nc, 0);
 			if (nc < 0) { fits = false; break; }

@@ -16,6 +16,7 @@ struct Rccl {
 	int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
 	int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
 	int (*CommDestroy)(Comm) = nullptr;
+	int (*CommAbort)(Comm) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
 	bool load()
 	{
@@ -26,6 +27,7 @@ struct Rccl {
 		CommInitRank = (int (*)(Comm*, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
 		Broadcast = (int (*)(const void*, void*, size_t, int, int, Comm, hipStream_t))dlsym(h, "ncclBroadcast");
 		CommDestroy = (int (*)(Comm))dlsym(h, "ncclCommDestroy");
+		CommAbort = (int (*)(Comm))dlsym(h, "ncclCommAbort");
 		GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
 		return GetUniqueId && CommInitRank && Broadcast && CommDestroy;
 	}
@@ -107,20 +109,25 @@ extern "C" int bwahip_init_rccl(const char *prefix, int rank, int world, const v
 	std::vector<uint8_t> meta;
 	DevBuf d_meta;
 	uint64_t meta_len = 0;
+	bool collective_failure = false;                           // every rank leaves together: the communicator can be destroyed normally
 	UniqueId id;
 	memcpy(&id, id128, 128);
 	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = BWAHIP_ENODEV; goto done; }
-	RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+	// rank 0 reads and packs the index BEFORE the communicator exists: whatever can fail on one rank alone (files, host memory) has then
+	// either happened or not, and the first thing broadcast is rank 0's verdict -- the metadata length, 0 = "rank 0 failed" -- so that
+	// every rank returns BWAHIP_EIO together instead of waiting in a broadcast that never comes
 	if (rank == 0) {
-		if ((rc = bwahip_load_index_files(prefix, &full))) goto done;
-		meta = pack_meta(full);
-		meta_len = meta.size();
+		const int lrc = bwahip_load_index_files(prefix, &full);
+		if (!lrc) { meta = pack_meta(full); meta_len = meta.size(); }
+		else { fprintf(stderr, "[bwahip] rank 0 could not load %s: the other ranks are told\n", prefix); meta_len = 0; }
 	}
-	// 1. metadata: length (8 bytes), then the blob
+	RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+	// 1. metadata: length (8 bytes; 0: rank 0 has no index), then the blob
 	if ((rc = d_meta.ensure(64))) goto done;
 	if (rank == 0 && hipMemcpyAsync(d_meta.p, &meta_len, 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BWAHIP_ENODEV; goto done; }
 	RCCL_TRY(g_rccl.Broadcast(d_meta.p, d_meta.p, 8, NCCL_UINT8, 0, comm, st));
 	if (hipMemcpyAsync(&meta_len, d_meta.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = BWAHIP_ENODEV; goto done; }
+	if (meta_len == 0) { rc = BWAHIP_EIO; collective_failure = true; goto done; }      // agreed by all ranks: a clean shutdown of the communicator
 	if (meta_len < sizeof(MetaHdr) || meta_len > (1ull << 32)) { rc = BWAHIP_EIO; goto done; }
 	if ((rc = d_meta.ensure(meta_len))) goto done;
 	if (rank == 0 && hipMemcpyAsync(d_meta.p, meta.data(), meta_len, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BWAHIP_ENODEV; goto done; }
@@ -138,9 +145,15 @@ extern "C" int bwahip_init_rccl(const char *prefix, int rank, int world, const v
 			if (hipMemcpyAsync(c->d_bwt.p, full.bwt.bwt, n_bwt, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(c->d_sa.p, full.bwt.sa, n_sa, hipMemcpyHostToDevice, st) != hipSuccess ||
 			    hipMemcpyAsync(c->d_pac.p, full.pac, n_pac, hipMemcpyHostToDevice, st) != hipSuccess) { rc = BWAHIP_ENODEV; goto done; }
 		}
-		RCCL_TRY(g_rccl.Broadcast(c->d_bwt.p, c->d_bwt.p, n_bwt, NCCL_UINT8, 0, comm, st));
-		RCCL_TRY(g_rccl.Broadcast(c->d_sa.p, c->d_sa.p, n_sa, NCCL_UINT8, 0, comm, st));
-		RCCL_TRY(g_rccl.Broadcast(c->d_pac.p, c->d_pac.p, n_pac, NCCL_UINT8, 0, comm, st));
+		// in pieces of 1 GiB: the element count of one call stays far below 2^31 whatever the library's internal index type is
+		for (int arr = 0; arr < 3; ++arr) {
+			uint8_t *p = (uint8_t*)(arr == 0 ? c->d_bwt.p : arr == 1 ? c->d_sa.p : c->d_pac.p);
+			const size_t total = arr == 0 ? n_bwt : arr == 1 ? n_sa : n_pac;
+			for (size_t o = 0; o < total; o += (size_t)1 << 30) {
+				const size_t len = total - o < ((size_t)1 << 30) ? total - o : (size_t)1 << 30;
+				RCCL_TRY(g_rccl.Broadcast(p + o, p + o, len, NCCL_UINT8, 0, comm, st));
+			}
+		}
 		// host copy of the packed reference (finalisation on host threads, when that knob is used)
 		c->host.pac = (uint8_t*)malloc(n_pac);
 		if (!c->host.pac) { rc = BWAHIP_ENOMEM; goto done; }
@@ -150,7 +163,9 @@ extern "C" int bwahip_init_rccl(const char *prefix, int rank, int world, const v
 done:
 	d_meta.release();
 	bwahip_free_host_index(&full);
-	if (comm) g_rccl.CommDestroy(comm);
+	// a failure of THIS rank alone after the communicator exists would leave the others waiting in their next broadcast: abort the
+	// communicator (its peers' pending operations then fail) instead of destroying it quietly
+	if (comm) { if (rc && !collective_failure && g_rccl.CommAbort) g_rccl.CommAbort(comm); else g_rccl.CommDestroy(comm); }
 	if (st) (void)hipStreamDestroy(st);
 	if (rc) { bwahip_destroy(c); return rc; }
 	*out = c;

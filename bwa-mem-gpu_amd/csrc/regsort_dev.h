@@ -53,19 +53,22 @@ __device__ __forceinline__ bool wave_rank_sort(const RegSort c, int n, int *idx,
 //   work: 8-byte aligned global scratch of ws_work_ints(n) ints; stk: 240 ints (LDS); lds: 256 words of LDS.
 // false (idx untouched): the introsort's depth limit was reached or n > 65535 -- the caller runs rs_introsort on one lane.
 __device__ __forceinline__ size_t ws_work_ints(int n) { return is_scratch_ints(n) + (size_t)n + (size_t)n / 4 + 4; }
-__device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int *stk, unsigned *lds, int l)
+//   v_lds (optional): v_cap words of LDS for the packed elements -- the partition steps then run on LDS instead of global memory
+__device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int *stk, unsigned *lds, int l, unsigned *v_lds = nullptr, int v_cap = 0)
 {
 	if (n > 65535) return false;
 	int *qs_scratch = work;
-	unsigned *v = reinterpret_cast<unsigned*>(work + is_scratch_ints(n));
-	uint8_t *tied = reinterpret_cast<uint8_t*>(v + n);
+	unsigned *v = n <= v_cap ? v_lds : reinterpret_cast<unsigned*>(work + is_scratch_ints(n));
+	uint8_t *tied = reinterpret_cast<uint8_t*>(work + is_scratch_ints(n) + n);
 	RegKey *tile = reinterpret_cast<RegKey*>(lds);               // 64 keys of 16 bytes
 	unsigned long long any_tie = 0;
-	for (int base = 0; base < n; base += 64) {
-		const int t = base + l;
-		RegKey kt; kt.k64 = 0; kt.score = 0; kt.qb = 0;
-		if (t < n) kt = c.key[t];
-		int cnt = 0; bool tie = false;
+	// count of smaller keys (and "has an equal one") of every element: four elements per lane and pass, the keys they are compared with
+	// coming by in tiles of 64 through LDS -- n^2 / 64 comparisons per lane, n / 256 tile loads per 256 elements
+	for (int base = 0; base < n; base += 256) {
+		RegKey kt[4];
+		int cnt[4] = { 0, 0, 0, 0 }; bool tie[4] = { false, false, false, false };
+#pragma unroll
+		for (int e = 0; e < 4; ++e) { const int t = base + 64 * e + l; kt[e].k64 = 0; kt[e].score = 0; kt[e].qb = 0; if (t < n) kt[e] = c.key[t]; }
 		for (int ub = 0; ub < n; ub += 64) {
 			is_sync();
 			if (ub + l < n) tile[l] = c.key[ub + l];
@@ -73,18 +76,25 @@ __device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int
 			const int hi = n - ub < 64 ? n - ub : 64;
 			for (int u = 0; u < hi; ++u) {
 				const RegKey ku = tile[u];
-				bool lt_ut, eq;
-				if (c.mode == 0) { lt_ut = ku.k64 < kt.k64; eq = ku.k64 == kt.k64; }
-				else {
-					eq = ku.score == kt.score && ku.k64 == kt.k64 && ku.qb == kt.qb;
-					lt_ut = ku.score > kt.score || (ku.score == kt.score && (ku.k64 < kt.k64 || (ku.k64 == kt.k64 && ku.qb < kt.qb)));
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					bool lt_ut, eq;
+					if (c.mode == 0) { lt_ut = ku.k64 < kt[e].k64; eq = ku.k64 == kt[e].k64; }
+					else {
+						eq = ku.score == kt[e].score && ku.k64 == kt[e].k64 && ku.qb == kt[e].qb;
+						lt_ut = ku.score > kt[e].score || (ku.score == kt[e].score && (ku.k64 < kt[e].k64 || (ku.k64 == kt[e].k64 && ku.qb < kt[e].qb)));
+					}
+					cnt[e] += lt_ut ? 1 : 0;
+					tie[e] |= eq && ub + u != base + 64 * e + l;
 				}
-				cnt += lt_ut ? 1 : 0;
-				tie |= eq && ub + u != t;
 			}
 		}
-		if (t < n) { v[t] = (unsigned)cnt << 16 | (unsigned)t; tied[t] = tie ? 1 : 0; }
-		any_tie |= __ballot(t < n && tie);
+#pragma unroll
+		for (int e = 0; e < 4; ++e) {
+			const int t = base + 64 * e + l;
+			if (t < n) { v[t] = (unsigned)cnt[e] << 16 | (unsigned)t; tied[t] = tie[e] ? 1 : 0; }
+			any_tie |= __ballot(t < n && tie[e]);
+		}
 	}
 	is_sync();
 	if (!any_tie) {
@@ -93,7 +103,7 @@ __device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int
 		return true;
 	}
 	if (!wave_qs_phase(v, n, qs_scratch, stk, lds, l)) return false;
-	wave_final_place(v, n, tied, idx, l);
+	wave_final_place(v, n, tied, idx, lds, l);
 	return true;
 }
 

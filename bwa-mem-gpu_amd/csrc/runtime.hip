@@ -633,8 +633,8 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		el.chain_n = c->d_chain_n.as<int>(); el.reg_base = c->d_reg_base.as<int64_t>();
 		el.regs = c->d_regs.as<DevReg>(); el.reg_n = c->d_reg_n.as<int>(); el.tmp_regs = c->d_tmp_regs.as<DevReg>(); el.srt = c->d_srt.as<int>();
 		if (dump) { el.dbg_regs = c->d_dbg_regs.as<DevReg>(); el.dbg_reg_n = c->d_dbg_reg_n.as<int>(); }
-		if ((rc = c->d_perm.ensure((size_t)(n + 4) * 4))) return rc;
-		el.kept_seeds = c->d_kept_seeds.as<int>(); el.perm = c->d_perm.as<int>() + 4; el.perm_counts = c->d_perm.as<int>();
+		if ((rc = c->d_perm.ensure((size_t)(n + 8) * 4))) return rc;
+		el.kept_seeds = c->d_kept_seeds.as<int>(); el.perm = c->d_perm.as<int>() + 8; el.perm_counts = c->d_perm.as<int>();
 		el.counters = counters; el.err = err;
 		if ((rc = c->d_redo.ensure((size_t)(n + 4) * 4)) || (rc = c->d_big_t.ensure((size_t)BWAHIP_EXT_BIG_GRID * (BWAHIP_EXT_BIG_T + 64)))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 16, c->stream));

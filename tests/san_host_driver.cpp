@@ -9,7 +9,7 @@ extern "C" {
 #include "../oracle/ora.h"
 }
 #include <limits.h>
-int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);   // host_final.cpp
+extern "C" int bwahip_process_seqs_host(bwahip_ctx *ctx, const bwahip_opt_t *opt, int64_t n_processed, int n, bwahip_seq_t *seqs, const bwahip_pestat_t *pes0);   // host_final.cpp
 
 struct bwahip_ctx { HostIndex host; ora_index_t *oidx; };
 

@@ -27,6 +27,14 @@ def test_rccl_broadcast_init_one_rank(small_index, tmp_path):
         assert b"".join(c.process_seqs(names, seqs, quals, opt)) == want
 
 
+def test_rccl_broadcast_init_reports_a_missing_index_to_every_rank(tmp_path):
+    """Rank 0 loads the index before the communicator exists and broadcasts its verdict first (a zero metadata length): a missing file set is
+    BWAHIP_EIO on every rank, not a hang of the others in a broadcast that never comes (one-rank communicator here)."""
+    uid = bw.Context.rccl_unique_id()
+    with pytest.raises(bw.BwahipError):
+        bw.Context.from_rccl(str(tmp_path / "no_such_index"), 0, 1, uid)
+
+
 def test_two_contexts_sharing_the_index_run_batches_concurrently(small_index, tmp_path):
     """bwahip_ctx_clone: a second context on the same GPU (index arrays shared in HBM), both driven at once from two host threads
     (double buffering).  Every batch's SAM must equal the CPU path's whichever context took it, SE and PE."""
