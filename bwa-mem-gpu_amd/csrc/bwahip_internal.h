@@ -153,6 +153,7 @@ struct ChainLaunch {
 	unsigned long long *counters;
 	int *flt;                                    // 8 ints per seed slot: per-position data for k_chain_flt
 	int *heavy_list, *heavy_count;               // reads whose overlap filter is deferred to k_chain_flt
+	const int *seed_cnt; int *perm, *perm_counts;   // k_chain's launch order: reads with many seeds first, like sizes together (nullptr = identity)
 	int *big_list, *big_count; int big_min, big_max;   // reads with big_min < seeds <= big_max go to k_chain_big (nullptr: off)
 };
 int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipStream_t st3, hipEvent_t fork, hipEvent_t join, hipEvent_t join3);
@@ -180,6 +181,7 @@ struct ExtLaunch {
 };
 constexpr int BWAHIP_EXT_BIG_GRID = 128, BWAHIP_EXT_BIG_T = 1 << 16;
 int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
+int launch_order(int n, const int *keys, int t0, int t1, int t2, int *perm, int *counts, hipStream_t st);   // launch order by classes of keys[r], heaviest first
 int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st);
 
 // ---- finalisation on the GPU (k_final.hip): mark primary -> alignments (CIGAR, NM, MD, mapQ) -> SAM text ----
@@ -226,6 +228,7 @@ struct FinLaunch {
 	DevAln *alns;
 	uint8_t *pool; unsigned long long *pool_head; unsigned long long pool_cap;   // CIGAR / MD text: bump allocation
 	int *redo_list, *redo_n; uint8_t *big_z;     // tasks whose backtrack matrix / window exceed LDS (k_cigar_big)
+	unsigned *zslab;                             // k_cigar (DP tasks): one slab of backtrack cells per workgroup (cigar_zslab_bytes)
 	// SAM text
 	const uint8_t *qual; const int64_t *qual_off;   // qualities: read r at qual + qual_off[r], or qual_off[r] < 0: none ('*')
 	const uint8_t *names; const int64_t *name_off; const uint8_t *comments; const int64_t *comment_off;   // per read (comments may be null)
@@ -241,6 +244,7 @@ int launch_task_fill(const FinLaunch &a, hipStream_t st);
 int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_cigar_big(const FinLaunch &a, int grid, hipStream_t st);   // the tasks k_cigar listed in redo_list; big_z: grid slabs of cigar_big_slab_bytes()
 size_t cigar_big_slab_bytes();
+size_t cigar_zslab_bytes(int max_len, int n_dp);
 int launch_sam(const FinLaunch &a, bool write, hipStream_t st, int read_lo = 0, int read_hi = -1);   // reads [read_lo, read_hi) (default: all)
 
 // ---- paired-end stages on the GPU (k_pair.hip): insert-size histogram, mate rescue, pairing ----

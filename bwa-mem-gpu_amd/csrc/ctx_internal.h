@@ -45,7 +45,7 @@ struct Knobs {
 	int intv_cap = 96;          // BWAHIP_INTV_CAP: initial per-read interval capacity (grown on overflow)
 	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
 	int heavy_mult = 10;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never)
-	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which k_chain_big takes the read (< 0: off)
+	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which a wavefront-per-read chaining kernel takes the read (< 0: off)
 	int rank_sort_min = 2;      // BWAHIP_RANK_SORT_MIN: dedup lists at least this long are sorted by the whole wavefront (shorter: the one-lane restatement of ks_introsort)
 	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
 	int ext_lds_window = 1 << 30;   // BWAHIP_EXT_LDS_WINDOW: reference windows above this go to k_extend_big (tests; default = the compiled LDS window)
@@ -101,7 +101,7 @@ struct bwahip_ctx {
 	// K3/K4 working set (sized from the seed count of the batch)
 	DevBuf d_cw, d_nxt, d_ord, d_wts, d_kept, d_first, d_keep, d_nodes, d_stack;
 	DevBuf d_chains, d_chain_seeds, d_chain_n, d_kept_seeds, d_reg_base, d_regs, d_tmp_regs, d_reg_n, d_srt;
-	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t, d_dedup;
+	DevBuf d_dbg_chains, d_dbg_seeds, d_dbg_chain_n, d_dbg_regs, d_dbg_reg_n, d_flt, d_heavy, d_perm, d_spec_regs, d_spec_items, d_scan, d_chain_big, d_redo, d_big_t, d_dedup, d_cperm;
 	// finalisation on the GPU (final_rt.hip)
 	DevBuf d_ctg_names, d_ctg_name_off, d_ctg_anno, d_ctg_anno_off, d_rg;      // contig names / annotations (SAM RNAME, XR), read-group id
 	DevBuf d_qual, d_qual_off, d_names, d_name_off, d_comments, d_comment_off; // per-batch text inputs of the SAM kernels
@@ -111,6 +111,7 @@ struct bwahip_ctx {
 	unsigned long long last_pe_counters[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // mate-rescue alignments run / regions added / most per pair / pairs rescued
 	DevBuf d_task_lists;                 // k_cigar's two work lists (no-DP tasks, DP tasks)
 	DevBuf d_resc_flag;                  // one byte per pair: mate rescue works on it (finalised by the second k_mark / k_pair launch)
+	DevBuf d_zslab;                      // k_cigar's backtrack slabs
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
 	HostBuf h_stage, h_sam, h_sam2;       // pinned staging: batch text in, SAM text out (two buffers taken in turn by bwahip_process_seqs_text)
 	int sam_flip = 0;

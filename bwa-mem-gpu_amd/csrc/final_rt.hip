@@ -263,6 +263,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 		f.pool = c->d_pool.as<uint8_t>(); f.pool_cap = want_pool;
 		HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 120, c->stream));   // pool head, redo count, error; the task-list lengths at +120 stay
 		{ const unsigned long long head0 = (unsigned long long)Tn * 64; HIP_TRY(hipMemcpyAsync(c->d_fmisc.p, &head0, 8, hipMemcpyHostToDevice, c->stream)); }   // the shared tail starts behind the slots
+		if (n_list[1] > 0) { if ((rc = c->d_zslab.ensure(cigar_zslab_bytes(c->max_len, n_list[1])))) return rc; f.zslab = c->d_zslab.as<unsigned>(); }
 		if ((rc = launch_cigar(f, n_list[0], n_list[1], c->max_len, c->stream, c->stream2, c->ev_fork, c->ev_join))) return rc;
 		int h[6] = { 0 };
 		HIP_TRY(hipMemcpyAsync(h, c->d_fmisc.p, 24, hipMemcpyDeviceToHost, c->stream));

@@ -11,8 +11,10 @@
 //   in : seeds of the read in look-up order (K2), sorted intervals (K1) for l_rep
 //   out: filtered chains in final order with their seeds contiguous; optional pre-filter dump
 #include "bwahip_internal.h"
+#include "regsort_dev.h"
 
 namespace {
+using wv::RegKey; using wv::RegSort;
 
 constexpr int BT_T = 6, BT_MAXK = 2 * BT_T - 1;              // kbtree.h:59 with sizeof(mem_chain_t) = 32
 constexpr int FLT_SEQ_MAX = 32;                              // more chains than this: filter in k_chain_flt
@@ -32,6 +34,7 @@ struct ReadCtx {
 	int *nxt;
 	BtNode *nodes; int n_nodes, root;
 	bool coop; int lane;                                        // k_chain_big: the 64 lanes run the read together (uniform control flow)
+	bool glb;                                                   // ... with the nodes in global memory (no LDS variant holds the read)
 	int *ord, *wts, *kept, *first, *keep_list, *stack;
 };
 
@@ -130,10 +133,12 @@ __device__ void bt_put(ReadCtx &c, int k)
 // ---- k_chain_big: the same B-tree, driven by a whole wavefront.  Control flow is uniform (every lane executes the read);
 // inside a node the lanes split the work: lane m holds key m, so the search is one compare and a ballot, and the
 // shifts of an insert / split are one element per lane.  Nodes live in LDS; lane 0 does the single-element stores.
-__device__ __forceinline__ void wsync()
+__device__ __forceinline__ void wsync(bool global_nodes = false)
 {
 	// orders the LDS node accesses of the lanes of this wavefront; deliberately NOT a full fence: waiting for the
-	// outstanding global stores (chain records, seed links) several times per seed was the cost of this kernel
+	// outstanding global stores (chain records, seed links) several times per seed was the cost of this kernel.
+	// global_nodes (reads beyond the LDS variants: their nodes live in global memory): the full fence it is.
+	if (global_nodes) { __threadfence_block(); __syncthreads(); return; }
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
@@ -182,14 +187,14 @@ __device__ void wbt_split(ReadCtx &c, int xi, int i, int yi)
 	if (l > i && l <= xn) sptr = x->ptr[l];
 	if (l >= i && l < xn) { sk = x->key[l]; spos = x->pos[l]; }
 	const int upk = y->key[BT_T - 1]; const int64_t uppos = y->pos[BT_T - 1];
-	wsync();
+	wsync(c.glb);
 	if (l < BT_T - 1) { z->key[l] = mk; z->pos[l] = mpos; }
 	if (y_internal && l < BT_T) z->ptr[l] = mp;
 	if (l > i && l <= xn) x->ptr[l + 1] = sptr;
 	if (l >= i && l < xn) { x->key[l + 1] = sk; x->pos[l + 1] = spos; }
-	wsync();
+	wsync(c.glb);
 	if (l == 0) { z->n = BT_T - 1; y->n = BT_T - 1; x->ptr[i + 1] = zi; x->key[i] = upk; x->pos[i] = uppos; x->n = xn + 1; }
-	wsync();
+	wsync(c.glb);
 }
 __device__ void wbt_put(ReadCtx &c, int k, int64_t pos)
 {
@@ -197,7 +202,7 @@ __device__ void wbt_put(ReadCtx &c, int k, int64_t pos)
 	if (c.nodes[c.root].n == BT_MAXK) {
 		const int s = wbt_new(c, 1);
 		if (l == 0) c.nodes[s].ptr[0] = c.root;
-		wsync();
+		wsync(c.glb);
 		wbt_split(c, s, 0, c.root);
 		c.root = s;
 	}
@@ -209,10 +214,10 @@ __device__ void wbt_put(ReadCtx &c, int k, int64_t pos)
 			const int i = wbt_find(x, pos, l, &r), n = x->n;
 			int sk = 0; int64_t spos = 0;
 			if (l > i && l < n) { sk = x->key[l]; spos = x->pos[l]; }
-			wsync();
+			wsync(c.glb);
 			if (l > i && l < n) { x->key[l + 1] = sk; x->pos[l + 1] = spos; }
 			if (l == 0) { x->key[i + 1] = k; x->pos[i + 1] = pos; x->n = n + 1; }
-			wsync();
+			wsync(c.glb);
 			return;
 		}
 		int i = wbt_find(x, pos, l, &r) + 1;
@@ -371,20 +376,24 @@ __device__ void write_chains(const ReadCtx &c, const DevIndex &ix, int n, const 
 // visits, ~10 per seed, and a 2 000-seed read otherwise sets the duration of the whole launch through L2 latency.
 constexpr int BIG_NODES = 800;                               // 800 x 192 B = 150 KB of LDS; nodes <= 0.24 x seeds + a few
 constexpr int MID_NODES = 400, MID_SEEDS = 1536;             // two workgroups per CU for the (far more common) reads up to 1536 seeds
+constexpr int SMALL_NODES = 72, SMALL_SEEDS = 256;           // eleven per CU for reads of a few dozen to 256 seeds (14 KB)
+constexpr int GLB_LDS = 2048;                                // reads beyond big_max seeds: nodes in their global slots, this much LDS for the sort's small tables
+// classes of the wavefront-per-read kernels: 0 = up to SMALL_SEEDS, 1 = up to MID_SEEDS, 2 = up to big_max, 3 = beyond (global nodes)
+__device__ __forceinline__ int coop_class(int S, int big_max) { return S <= SMALL_SEEDS ? 0 : S <= MID_SEEDS ? 1 : S <= big_max ? 2 : 3; }
 
 template <bool BIG>
-__device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *lds_nodes, int lds_node_cap = BIG_NODES)
+__device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *lds_nodes, int lds_node_cap = BIG_NODES, uint8_t *lds_area = nullptr, int lds_bytes = 0)
 {
 	const int64_t sb = a.seed_base[r];
 	const int S = (int)(a.seed_base[r + 1] - sb), len = (int)(a.off[r + 1] - a.off[r]);
-	if (!BIG && a.big_list && S > a.big_min && S <= a.big_max) return;   // k_chain_big's (listed by k_chain_classify); it runs concurrently: touch nothing
+	if (!BIG && a.big_list && S > a.big_min) return;               // a wavefront-per-read kernel's (listed by k_chain_classify); they run concurrently: touch nothing
 	ReadCtx c;
 	c.seeds = a.seeds + sb; c.n_seeds = S;
 	c.cw = reinterpret_cast<ChainW*>(a.cw_) + sb; c.nxt = a.nxt + sb; c.ord = a.ord + sb; c.wts = a.wts + sb; c.kept = a.kept + sb; c.first = a.first + sb;
 	c.keep_list = a.keep_list + sb;
-	c.nodes = BIG ? lds_nodes : reinterpret_cast<BtNode*>(a.nodes_) + (sb >> 2) + 4 * (int64_t)r;
+	c.nodes = BIG && lds_nodes ? lds_nodes : reinterpret_cast<BtNode*>(a.nodes_) + (sb >> 2) + 4 * (int64_t)r;   // (class 3: the read's global node slots)
 	c.stack = a.stack + 256 * (int64_t)r;
-	c.n_chains = 0; c.n_nodes = 0; c.coop = BIG; c.lane = (int)(threadIdx.x & 63);
+	c.n_chains = 0; c.n_nodes = 0; c.coop = BIG; c.lane = (int)(threadIdx.x & 63); c.glb = BIG && !lds_nodes;
 	a.chain_n[r] = 0; a.kept_seeds[r] = 0;
 	if (a.dbg_chain_n) a.dbg_chain_n[r] = 0;
 	if (S == 0) return;
@@ -407,7 +416,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 	const unsigned long long t_0 = wall_clock64();
 	// greedy chaining (bwamem.c:280-308)
 	c.root = BIG ? wbt_new(c, 0) : bt_new(c, 0);
-	if (BIG) wsync();
+	if (BIG) wsync(c.glb);
 	DevSeed sd_next = c.seeds[0];                               // the next seed is fetched one iteration ahead of its use
 	for (int si = 0; si < S; ++si) {
 		const DevSeed sd = sd_next;
@@ -423,7 +432,7 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 			ch->pos = sd.rbeg; ch->head = ch->tail = si; ch->n = 1; ch->rid = sd.rid;
 			ch->last_rbeg = sd.rbeg; ch->first_qbeg = ch->last_qbeg = sd.qbeg; ch->last_len = sd.len; ch->pad = 0;
 			c.nxt[si] = -1;
-			if (BIG) { wsync(); wbt_put(c, c.n_chains++, sd.rbeg); } else bt_put(c, c.n_chains++);
+			if (BIG) { wsync(c.glb); wbt_put(c, c.n_chains++, sd.rbeg); } else bt_put(c, c.n_chains++);
 		}
 	}
 	const unsigned long long t_1 = wall_clock64();
@@ -455,21 +464,35 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 	n_chn = k;
 	if (n_chn == 0) return;
 	if (BIG) {
-		// the exact unstable introsort runs on one lane; the B-tree is no longer needed, so its LDS holds the index array
-		// and the weights while it runs (what the sort waits for is the latency of its fetches)
-		int *l_ord = reinterpret_cast<int*>(lds_nodes), *l_wts = l_ord + n_chn, *l_stk = l_wts + c.n_chains;
-		const bool fits = (size_t)(n_chn + c.n_chains + 256) * 4 <= (size_t)lds_node_cap * sizeof(BtNode);
-		if (fits) {
-			for (int i = c.lane; i < n_chn; i += 64) l_ord[i] = c.ord[i];
-			for (int i = c.lane; i < c.n_chains; i += 64) l_wts[i] = c.wts[i];
-			wsync();
-			if (c.lane == 0) { ReadCtx cl = c; cl.wts = l_wts; cl.stack = l_stk; isort_weight(cl, n_chn, l_ord); }
-			wsync();
-			for (int i = c.lane; i < n_chn; i += 64) c.ord[i] = l_ord[i];
-			__threadfence_block(); __builtin_amdgcn_wave_barrier();
-		} else {
+		// ks_introsort by weight (bwamem.c:331-332,348), heavier first: the whole wavefront follows the reference's introsort exactly, ties
+		// included (isort_dev.h); the B-tree is no longer needed, so its LDS (or, for the reads with global nodes, the filter's scratch of
+		// the read, free until the filter) holds the keys, the index array and the sort's tables.  The one-lane restatement takes over only
+		// at the introsort's depth limit.
+		uint8_t *area = lds_nodes ? lds_area : reinterpret_cast<uint8_t*>(a.flt + 8 * sb);
+		const size_t area_bytes = lds_nodes ? (size_t)lds_bytes : (size_t)S * 32;
+		// layout: keys[n] (16 B) | idx[n] | work (8-byte aligned) ; the stack and the 256-word table always in LDS
+		int *stk = reinterpret_cast<int*>(lds_nodes ? lds_area + lds_bytes - 2048 : lds_area);
+		unsigned *tab = reinterpret_cast<unsigned*>(stk + 256);
+		const size_t need = (size_t)n_chn * 20 + 8 + wv::ws_work_ints(n_chn) * 4 + (lds_nodes ? 2048 : 0);
+		bool sorted = false;
+		if (need <= area_bytes && n_chn >= 2) {
+			RegKey *keys = reinterpret_cast<RegKey*>(area);
+			int *idx = reinterpret_cast<int*>(keys + n_chn);
+			int *work = idx + n_chn + (n_chn & 1);
+			for (int i = c.lane; i < n_chn; i += 64) { keys[i].k64 = -(int64_t)c.wts[c.ord[i]]; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
+			__threadfence_block(); __syncthreads();
+			sorted = wv::wave_sort_exact(RegSort{keys, 0}, n_chn, idx, work, stk, tab, c.lane);
+			__threadfence_block(); __syncthreads();
+			if (sorted) {                                           // positions -> chain ids, through the (free again) work area
+				for (int i = c.lane; i < n_chn; i += 64) work[i] = c.ord[idx[i]];
+				__threadfence_block(); __syncthreads();
+				for (int i = c.lane; i < n_chn; i += 64) c.ord[i] = work[i];
+				__threadfence_block(); __syncthreads();
+			}
+		}
+		if (!sorted && n_chn >= 2) {
 			if (c.lane == 0) isort_weight(c, n_chn, c.ord);
-			__threadfence_block(); __builtin_amdgcn_wave_barrier();
+			__threadfence_block(); __syncthreads();
 		}
 	} else isort_weight(c, n_chn, c.ord);                       // exact unstable introsort
 	const unsigned long long t_2 = wall_clock64();
@@ -540,36 +563,39 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 
 __global__ __launch_bounds__(64) void k_chain(ChainLaunch a)
 {
-	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r < a.n_reads) chain_read<false>(a, r, nullptr);
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	// one read per lane, in input order: packing the reads with many seeds into the same wavefronts was tried (launch order by seed count) and lost
+	// -- 64 lanes each walking its own B-tree of hundreds of chains evict each other from the caches (k_chain 8.9 -> 13.2 ms per million reads)
+	if (t < a.n_reads) chain_read<false>(a, t, nullptr);
 }
 
-// the reads k_chain_big takes (so that it can run beside k_chain on a second stream)
+// the reads the wavefront-per-read kernels take (so that they can run beside k_chain on other streams): four lists, one per class, in
+// big_list[class * n_reads ..]; big_count[class] = length, big_count[4 + class] = the class's work-queue head
 __global__ void k_chain_classify(ChainLaunch a)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= a.n_reads) return;
 	const int S = (int)(a.seed_base[r + 1] - a.seed_base[r]);
-	if (S > a.big_min && S <= a.big_max) {
-		// the few longest ones go to the front of the list (k_chain_big<BIG_NODES>, one workgroup per CU), the rest to the
-		// back (k_chain_big<MID_NODES>, two per CU); both kernels run beside k_chain on their own streams
-		if (S > MID_SEEDS) a.big_list[atomicAdd(&a.big_count[1], 1)] = r;
-		else a.big_list[a.n_reads - 1 - atomicAdd(&a.big_count[0], 1)] = r;
+	if (S > a.big_min) {
+		const int cls = coop_class(S, a.big_max);
+		a.big_list[(size_t)cls * a.n_reads + atomicAdd(&a.big_count[cls], 1)] = r;
 	}
 }
 
-template <int NODES, bool HI>
+template <int NODES, int CLS>
 __global__ __launch_bounds__(64) void k_chain_big(ChainLaunch a)
 {
-	__shared__ BtNode nodes[NODES];
-	const int n_mine = a.big_count[HI ? 1 : 0];
+	constexpr int LDS_BYTES = NODES > 0 ? NODES * (int)sizeof(BtNode) : GLB_LDS;
+	__shared__ __attribute__((aligned(16))) uint8_t s_area[LDS_BYTES];
+	BtNode *nodes = NODES > 0 ? reinterpret_cast<BtNode*>(s_area) : nullptr;
+	const int n_mine = a.big_count[CLS];
 	for (;;) {                                                   // work queue: a workgroup that finishes takes the next read
 		int h = 0;
-		if ((threadIdx.x & 63) == 0) h = atomicAdd(&a.big_count[HI ? 2 : 3], 1);
+		if ((threadIdx.x & 63) == 0) h = atomicAdd(&a.big_count[4 + CLS], 1);
 		h = __shfl(h, 0);
 		if (h >= n_mine) break;
-		chain_read<true>(a, a.big_list[HI ? h : a.n_reads - 1 - h], nodes, NODES);
-		wsync();
+		chain_read<true>(a, a.big_list[(size_t)CLS * a.n_reads + h], nodes, NODES, s_area, LDS_BYTES);
+		__threadfence_block(); __syncthreads();
 	}
 }
 
@@ -687,11 +713,13 @@ int launch_chain_flt(const ChainLaunch &a, hipStream_t st)
 int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipStream_t st3, hipEvent_t fork, hipEvent_t join, hipEvent_t join3)
 {
 	if (a.n_reads <= 0) return 0;
-	if (a.big_list) {                                        // many-seed reads: own kernels, concurrent with the rest
+	if (a.big_list) {                                        // reads with more than big_min seeds: a wavefront each, in kernels that run beside k_chain
 		hipLaunchKernelGGL(k_chain_classify, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
 		if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess || hipStreamWaitEvent(st3, fork, 0) != hipSuccess) return BWAHIP_ENODEV;
-		hipLaunchKernelGGL((k_chain_big<BIG_NODES, true>), dim3(256), dim3(64), 0, st2, a);
-		hipLaunchKernelGGL((k_chain_big<MID_NODES, false>), dim3(1024), dim3(64), 0, st3, a);
+		hipLaunchKernelGGL((k_chain_big<0, 3>), dim3(256), dim3(64), 0, st2, a);              // the longest first
+		hipLaunchKernelGGL((k_chain_big<BIG_NODES, 2>), dim3(256), dim3(64), 0, st2, a);
+		hipLaunchKernelGGL((k_chain_big<MID_NODES, 1>), dim3(1024), dim3(64), 0, st3, a);
+		hipLaunchKernelGGL((k_chain_big<SMALL_NODES, 0>), dim3(256 * 11), dim3(64), 0, st3, a);
 		if (hipEventRecord(join, st2) != hipSuccess || hipEventRecord(join3, st3) != hipSuccess) return BWAHIP_ENODEV;
 	}
 	hipLaunchKernelGGL(k_chain, dim3((a.n_reads + 63) / 64), dim3(64), 0, st, a);

@@ -24,6 +24,9 @@
 #include "wave_dev.h"
 #include "regsort_dev.h"
 
+#ifndef KEXT_W3
+#define KEXT_W3 7                                           // wavefronts per SIMD the extension kernels for reads below 192 bases are compiled for
+#endif
 namespace {
 using namespace wv;
 
@@ -424,6 +427,12 @@ __device__ __forceinline__ int wave_extend_fit(const Sw &sw, const uint8_t *q, i
                                                int w, int end_bonus, int zdrop, int h0, int &qle, int &tle, int &gtle, int &gscore, int &max_off, Work &wk, unsigned *s_he)
 {
 	if (qlen < 64) return wave_extend<1>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+#ifdef KEXT_NO_WINDOW
+	if (CPL > 2 && qlen < 128) return wave_extend<2>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	if (CPL > 3 && qlen < 192) return wave_extend<3>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	if (CPL > 4 && qlen < 256) return wave_extend<4>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+	return wave_extend<CPL>(sw, q, qs, qlen, t, ts, tlen, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off, wk);
+#endif
 	const int e_ins = sw.e_ins, e_del = sw.e_del;
 	int wc = w;                                                  // ksw.c:399-407
 	{
@@ -568,7 +577,7 @@ constexpr int SPEC_NONE = -0x7fffffff - 1;                    // spec_regs[].sco
 // chain.  So the best seed of every chain of such a read is extended here, one wavefront per chain, and k_extend
 // picks the result up.  (A best seed that k_extend then skips was extended in vain; its result is never looked at.)
 template <int CPL>
-__global__ __launch_bounds__(64, (CPL <= 3 ? 7 : CPL == 4 ? 4 : 1)) void k_extend_spec(ExtLaunch a)
+__global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k_extend_spec(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
@@ -967,7 +976,7 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 
 template <int CPL>
 // (CPL <= 3: seven waves per SIMD at 72 VGPRs and 128 bytes of spill beat five at 96 VGPRs by 6 % -- measured back to back on one box)
-__global__ __launch_bounds__(64, (CPL <= 3 ? 7 : CPL == 4 ? 4 : 1)) void k_extend(ExtLaunch a)
+__global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k_extend(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
@@ -1014,21 +1023,21 @@ __global__ __launch_bounds__(64) void k_extend_big(ExtLaunch a)
 // Scheduling aid: reads with many seeds to extend go to the front of the launch order, the heaviest first, so that the long ones
 // start at once and the short ones fill in behind them (the order has no effect on results).  Four classes by the number of seeds
 // left after chain filtering; counts[0..3]: class sizes, counts[4..7]: cursors.
-__device__ __forceinline__ int order_class(int kept) { return kept >= 1024 ? 0 : kept >= 256 ? 1 : kept >= 64 ? 2 : 3; }
-__global__ void k_order_count(int n, const int *kept_seeds, int *counts)
+__device__ __forceinline__ int order_class(int v, int t0, int t1, int t2) { return v >= t0 ? 0 : v >= t1 ? 1 : v >= t2 ? 2 : 3; }
+__global__ void k_order_count(int n, const int *kept_seeds, int t0, int t1, int t2, int *counts)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	const int c = r < n ? order_class(kept_seeds[r]) : 3;
+	const int c = r < n ? order_class(kept_seeds[r], t0, t1, t2) : 3;
 	// one atomic per class and wavefront
 	for (int k = 0; k < 4; ++k) {
 		const unsigned long long m = __ballot(r < n && c == k);
 		if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&counts[k], __popcll(m));
 	}
 }
-__global__ void k_order_place(int n, const int *kept_seeds, int *perm, int *counts)
+__global__ void k_order_place(int n, const int *kept_seeds, int t0, int t1, int t2, int *perm, int *counts)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	const int c = r < n ? order_class(kept_seeds[r]) : 3;
+	const int c = r < n ? order_class(kept_seeds[r], t0, t1, t2) : 3;
 	const int l = threadIdx.x & 63;
 	for (int k = 0; k < 4; ++k) {
 		const unsigned long long m = __ballot(r < n && c == k);
@@ -1101,6 +1110,16 @@ int launch_kat_ksw(const DevOpt &opt, int n, const int *params, const uint8_t *q
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
+// perm[0..n): the reads ordered by class of keys[r] (>= t0, >= t1, >= t2, rest); counts: 8 ints of scratch
+int launch_order(int n, const int *keys, int t0, int t1, int t2, int *perm, int *counts, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	(void)hipMemsetAsync(counts, 0, 32, st);
+	hipLaunchKernelGGL(k_order_count, dim3((n + 255) / 256), dim3(256), 0, st, n, keys, t0, t1, t2, counts);
+	hipLaunchKernelGGL(k_order_place, dim3((n + 255) / 256), dim3(256), 0, st, n, keys, t0, t1, t2, perm, counts);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
 int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st)
 {
 	if (a.n_reads <= 0 || !a.spec_regs) return 0;
@@ -1118,9 +1137,7 @@ int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
 {
 	if (a.n_reads <= 0) return 0;
 	if (a.perm) {
-		(void)hipMemsetAsync(a.perm_counts, 0, 32, st);
-		hipLaunchKernelGGL(k_order_count, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.kept_seeds, a.perm_counts);
-		hipLaunchKernelGGL(k_order_place, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a.n_reads, a.kept_seeds, a.perm, a.perm_counts);
+		launch_order(a.n_reads, a.kept_seeds, 1024, 256, 64, a.perm, a.perm_counts, st);
 	}
 	// columns 0..max_len must fit in 64 lanes x CPL registers
 	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend<3>, dim3(a.n_reads), dim3(64), 0, st, a);

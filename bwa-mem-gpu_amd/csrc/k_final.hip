@@ -408,7 +408,11 @@ __device__ int wave_global_trace(const Sw &sw, const uint8_t *q, int qs, int qle
 // outside the band as in the row-wise form.  Every cell evaluates ksw.c:548-572 literally, so H, E, F and the backtrack bytes are
 // those of the reference whatever the order.  Needs w >= |tlen - qlen| (bwa.c:293-300 guarantees w >= |..| + 3): then no row is
 // empty and the last row reaches column qlen - 1.  Returns the score (ksw.c:583).
-__device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col)
+// GZ: the backtrack cells go to a global slab instead (zg, 64 words per block of 16 steps: word (s >> 4) * 64 + k holds lane k's eight cells of
+// those steps, 4 bits each) -- written with one coalesced store per 16 steps, so that the kernel's LDS holds nothing per cell and many more
+// tasks are in flight; the backtrack reads it back run by run (reg2aln).
+template <bool GZ>
+__device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col, unsigned *zg)
 {
 	const int k = lane();
 	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
@@ -426,6 +430,7 @@ __device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen,
 	int tn = ldt(i + 1), qn = ldq(j + 1);
 	const bool mine = k <= 2 * w;
 	int pend = 0;
+	unsigned acc = 0;
 	for (int s = 0; s <= steps; ++s) {
 		const int Ein = __builtin_amdgcn_update_dpp(NEG, Eout, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane k <- lane k + 1
 		const int Fin = __builtin_amdgcn_update_dpp(NEG, Fout, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane k <- lane k - 1
@@ -450,10 +455,12 @@ __device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen,
 			// 4 bits per cell (h source, e extended, f extended), rows 2r and 2r+1 of a diagonal in one byte at [r][k]: the lane writes the low
 			// nibble with the even row and the whole byte with the odd one (half the LDS of a byte per cell: more tasks in flight)
 			const int nib = (d & 3) | (d >> 2 & 1) << 2 | (d >> 5 & 1) << 3;
-			if (i & 1) z[(size_t)(i >> 1) * n_col + k] = (uint8_t)(pend | nib << 4); else { pend = nib; z[(size_t)(i >> 1) * n_col + k] = (uint8_t)nib; }
+			if (GZ) acc |= (unsigned)nib << (((s & 15) >> 1) << 2);
+			else if (i & 1) z[(size_t)(i >> 1) * n_col + k] = (uint8_t)(pend | nib << 4); else { pend = nib; z[(size_t)(i >> 1) * n_col + k] = (uint8_t)nib; }
 			Hd = h;
 			++i; ++j;
 		}
+		if (GZ && ((s & 15) == 15 || s == steps)) { zg[(size_t)(s >> 4) * 64 + k] = acc; acc = 0; }
 	}
 	return __builtin_amdgcn_readlane(Hd, k_last);
 }
@@ -462,7 +469,9 @@ __device__ int wave_band_trace(const Sw &sw, const uint8_t *q, int qs, int qlen,
 // of the even diagonal, odd steps the cell of the odd one -- both in row i = s/2 - k -- so every lane of the band works at every
 // step.  Inputs, all one step old: E of (i-1, 2k+1) and F of (i, 2k) are the lane's own; F of (i, 2k-1) comes from lane k - 1, E of
 // (i-1, 2k+2) from lane k + 1.
-__device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col)
+// GZ: as above, one byte (the lane's two cells of a row) per iteration, four iterations per word: word (it >> 2) * 64 + k, it = s / 2.
+template <bool GZ>
+__device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen, const uint8_t *t, int ts, int tlen, int w, uint8_t *z, int n_col, unsigned *zg)
 {
 	const int k = lane(), d0 = 2 * k, d1 = d0 + 1;
 	const int oe_del = sw.o_del + sw.e_del, oe_ins = sw.o_ins + sw.e_ins, e_del = sw.e_del, e_ins = sw.e_ins;
@@ -497,10 +506,12 @@ __device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen
 			Fo = f > tI ? f : tI;
 			// 4 bits per cell, the lane's two diagonals of a row in one byte at [row][lane]: low nibble with the even diagonal, whole byte with the odd one
 			const int nib = (dd & 3) | (dd >> 2 & 1) << 2 | (dd >> 5 & 1) << 3;
-			if (d & 1) z[(size_t)ii * n_col + k] = (uint8_t)(pend | nib << 4); else { pend = nib; z[(size_t)ii * n_col + k] = (uint8_t)nib; }
+			if (GZ) pend |= (d & 1) ? nib << 4 : nib;
+			else if (d & 1) z[(size_t)ii * n_col + k] = (uint8_t)(pend | nib << 4); else { pend = nib; z[(size_t)ii * n_col + k] = (uint8_t)nib; }
 			Hd = h;
 		}
 	};
+	unsigned acc = 0;
 	for (int s = 0; s <= steps; s += 2) {
 		pend = 0;
 		const int c0 = sc0, c1 = sc1;
@@ -511,6 +522,11 @@ __device__ int wave_band_trace2(const Sw &sw, const uint8_t *q, int qs, int qlen
 		const int Er = __builtin_amdgcn_update_dpp(NEG, E0, 0x130, 0xf, 0xf, false);   // wave_shl:1  E of lane k + 1's even diagonal (its cell of row i - 1 ... computed this step)
 		cell(d1, i, j0 + 1, c1, Er, F0, H1, E1, F1);
 		++i; ++j0;
+		if (GZ) {
+			const int it = s >> 1;
+			acc |= (unsigned)pend << ((it & 3) << 3);
+			if ((it & 3) == 3 || s + 2 > steps) { zg[(size_t)(it >> 2) * 64 + k] = acc; acc = 0; }
+		}
 	}
 	return __builtin_amdgcn_readlane((d_last & 1) ? H1 : H0, d_last >> 1);
 }
@@ -524,7 +540,7 @@ __device__ __forceinline__ int put_uint(uint8_t *dst, unsigned v)
 	return n;
 }
 
-struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; int max_c, max_md; };   // max_c / max_md: capacity of cig / md
+struct CigarLds { uint8_t *q, *t, *z; uint32_t *cig; uint8_t *md; int8_t *mat; int max_c, max_md; unsigned *zg; };   // zg != nullptr: band kernels keep their backtrack cells in this global slab (k_cigar)   // max_c / max_md: capacity of cig / md
 
 // One task: region `ar` of read r -> DevAln (+ CIGAR words and MD text appended to the pool).  BIG: window / matrix in the
 // workgroup's global slab.  Returns false when the task does not fit this variant (caller lists it for k_cigar_big).
@@ -585,17 +601,19 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 			const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
 			const bool nib_z = 2 * w + 1 <= 64;                     // band of at most 64 diagonals: 4-bit cells, two rows per byte (wave_band_trace)
 			const bool nib2_z = !nib_z && 2 * w + 1 <= 128;          // up to 128: 4-bit cells, a lane's two diagonals per byte (wave_band_trace2)
-			if ((nib_z ? (size_t)((rlen + 1) >> 1) * (size_t)(2 * w + 1) : nib2_z ? (size_t)rlen * (size_t)(w + 1) : (size_t)n_col * (size_t)rlen) > z_cap) { fits = false; break; }
+			const bool gz = !BIG && m.zg != nullptr;                   // k_cigar: band cells in the global slab, nothing wider than 128 diagonals
+			if (gz ? !(nib_z || nib2_z) : (nib_z ? (size_t)((rlen + 1) >> 1) * (size_t)(2 * w + 1) : nib2_z ? (size_t)rlen * (size_t)(w + 1) : (size_t)n_col * (size_t)rlen) > z_cap) { fits = false; break; }
 			__syncthreads();
 			// the fewest columns per lane that hold the query; CPLMAX (from the longest read of the batch) bounds what is
 			// compiled in, and with it the registers of the kernel
-			if (nib_z) score = wave_band_trace(sw, qp, qs, lq, tp, ts, rlen, w, m.z, 2 * w + 1);   // (row stride = diagonals of the band)
-			else if (nib2_z) score = wave_band_trace2(sw, qp, qs, lq, tp, ts, rlen, w, m.z, w + 1);   // (row stride = lanes of the band)
-			else if (lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else if (CPLMAX <= 2 || lq < 128) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else if (CPLMAX <= 3 || lq < 192) score = wave_global_trace<(CPLMAX < 3 ? CPLMAX : 3)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else if (CPLMAX <= 4 || lq < 256) score = wave_global_trace<(CPLMAX < 4 ? CPLMAX : 4)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
-			else score = wave_global_trace<CPLMAX>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			if (!BIG && gz) score = nib_z ? wave_band_trace<true>(sw, qp, qs, lq, tp, ts, rlen, w, nullptr, 0, m.zg) : wave_band_trace2<true>(sw, qp, qs, lq, tp, ts, rlen, w, nullptr, 0, m.zg);
+			else if (nib_z) score = wave_band_trace<false>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, 2 * w + 1, nullptr);   // (row stride = diagonals of the band)
+			else if (nib2_z) score = wave_band_trace2<false>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, w + 1, nullptr);   // (row stride = lanes of the band)
+			else if (BIG && lq < 64) score = wave_global_trace<1>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (BIG && (CPLMAX <= 2 || lq < 128)) score = wave_global_trace<(CPLMAX < 2 ? CPLMAX : 2)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (BIG && (CPLMAX <= 3 || lq < 192)) score = wave_global_trace<(CPLMAX < 3 ? CPLMAX : 3)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (BIG && (CPLMAX <= 4 || lq < 256)) score = wave_global_trace<(CPLMAX < 4 ? CPLMAX : 4)>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
+			else if (BIG) score = wave_global_trace<CPLMAX>(sw, qp, qs, lq, tp, ts, rlen, w, m.z, n_col);
 			wsync();
 			// ---- backtrack (ksw.c:586-603); operations are produced last to first and reversed afterwards.  The walk is a chain of dependent
 			// reads of z, but nearly all of its steps are diagonal ones in state 0 (match / mismatch): there the next cells are known in
@@ -610,6 +628,13 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 					else { if (have) { if (nc < m.max_c) { if (l == 0) m.cig[nc] = cur; } else ovf = true; ++nc; } cur = (uint32_t)len << 4 | (uint32_t)op; have = true; }
 				};
 				auto cell = [&](int ii, int kk) -> int {              // the z byte of ksw.c:551-572 for cell (row ii, column kk)
+					if (gz) {
+						const int kd = kk - ii + w;
+						int nb;
+						if (nib_z) { const int st = 2 * ii + kd; nb = (int)(m.zg[(size_t)(st >> 4) * 64 + kd] >> (((st & 15) >> 1) << 2)) & 15; }
+						else { const int kl = kd >> 1, it = ii + kl; const int byte = (int)(m.zg[(size_t)(it >> 2) * 64 + kl] >> ((it & 3) << 3)) & 255; nb = (kd & 1) ? byte >> 4 : byte & 15; }
+						return (nb & 3) | (nb >> 2 & 1) << 2 | (nb >> 3 & 1) << 5;
+					}
 					if (nib_z || nib2_z) {
 						const int kd = kk - ii + w;
 						const int byte = nib_z ? m.z[(size_t)(ii >> 1) * (2 * w + 1) + kd] : m.z[(size_t)ii * (w + 1) + (kd >> 1)];
@@ -745,35 +770,41 @@ __device__ __forceinline__ bool reg2aln(const FinLaunch &a, const FinReg &ar, in
 	return true;
 }
 
-// FAST: the tasks of fast_list (no DP: no backtrack matrix, one CIGAR operation) with a fifth of the LDS, so that several
-// times more of them are in flight -- the kernel waits on chains of dependent global loads, not on arithmetic
+// FAST: the tasks of fast_list (no DP: no backtrack matrix, one CIGAR operation), one task per workgroup.  DP tasks (FAST = false): a fixed
+// grid of workgroups takes them in turn; each owns a slab of global memory for the backtrack cells of the band kernels (written with
+// coalesced stores, read back run by run), so that LDS holds only the query, the reference span and the CIGAR / MD being built and the
+// number of tasks in flight is set by registers.  Bands wider than 128 diagonals, or texts beyond the staging arrays, go to k_cigar_big.
+constexpr int CG_TCAP_SMALL = 768;
+// wavefronts per SIMD k_cigar is compiled for: 6 (80 VGPRs) for reads below 192 bases, 5 (96) above -- measured: 5.9 vs 6.2 ms (150 bp) and
+// 44 vs 47 ms (250 bp at 5 %) per million reads; 8 (64 VGPRs, spilling) loses in both
+__host__ __device__ constexpr size_t cigar_zslab_words(int tcap) { return (size_t)(tcap + 72) * 16; }   // covers both band kernels: (tlen + w + 4) / 4 and (2 tlen + 2 w) / 16 blocks of 64 words
 template <bool FAST, int CPLMAX>
-__global__ __launch_bounds__(64) void k_cigar(FinLaunch a, int n_list)
+__global__ __launch_bounds__(64, (FAST || CPLMAX <= 3) ? 6 : 5) void k_cigar(FinLaunch a, int n_list)
 {
-	// LDS per task, sized by the read-length class of the batch (CPLMAX <= 3: reads below 192 bases; FAST tasks span exactly
-	// their query, at most BWAHIP_MAX_READ_LEN, and have one CIGAR operation): what does not fit goes to k_cigar_big.  The
-	// kernel waits on chains of dependent LDS / global loads, so the number of tasks in flight per CU is what matters
 	constexpr bool SMALL = FAST || CPLMAX <= 3;
-	constexpr int TCAP = SMALL ? 768 : CG_MAXT, ZL = FAST ? 16 : SMALL ? 5120 : CG_ZLDS, MC = FAST ? 8 : SMALL ? 160 : CG_MAXC, MMD = SMALL ? 512 : CG_MAXMD;
+	constexpr int TCAP = SMALL ? CG_TCAP_SMALL : CG_MAXT, MC = FAST ? 8 : SMALL ? 160 : CG_MAXC, MMD = SMALL ? 512 : CG_MAXMD;
 	__shared__ uint8_t s_q[CG_MAXQ + 8];
 	__shared__ uint8_t s_t[TCAP + 8];
-	__shared__ uint8_t s_z[ZL];
+	__shared__ uint8_t s_z[16];
 	__shared__ uint32_t s_cig[MC];
 	__shared__ uint8_t s_md[MMD];
 	__shared__ int8_t s_mat[32];
 	const int l = lane();
-	if ((int)blockIdx.x >= n_list) return;
-	const long long t = FAST ? a.fast_list[blockIdx.x] : a.dp_list[blockIdx.x];
-	const int2 tk = a.tasks[t];
-	const int r = tk.x;
-	const int l_query = (int)(a.off[r + 1] - a.off[r]);
-	const uint8_t *query = a.seq + a.off[r];
-	for (int i = l; i < l_query; i += 64) { const uint8_t c = query[i]; s_q[i] = c < 5 ? c : 4; }   // bwamem.c:1115: codes >= 5 -> 4 (already codes here)
 	if (l < 25) s_mat[l] = a.opt.mat[l];
-	__syncthreads();
-	const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
-	const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat, MC, MMD };
-	if (!reg2aln<false, FAST, CPLMAX>(a, ar, r, t, m, TCAP, FAST ? 0 : ZL, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
+	unsigned *zg = FAST ? nullptr : a.zslab + (size_t)blockIdx.x * cigar_zslab_words(TCAP);
+	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
+		const long long t = FAST ? a.fast_list[it] : a.dp_list[it];
+		const int2 tk = a.tasks[t];
+		const int r = tk.x;
+		const int l_query = (int)(a.off[r + 1] - a.off[r]);
+		const uint8_t *query = a.seq + a.off[r];
+		__syncthreads();
+		for (int i = l; i < l_query; i += 64) { const uint8_t c = query[i]; s_q[i] = c < 5 ? c : 4; }   // bwamem.c:1115: codes >= 5 -> 4 (already codes here)
+		__syncthreads();
+		const FinReg ar = a.fregs[a.reg_base[r] + tk.y];
+		const CigarLds m = { s_q, s_t, s_z, s_cig, s_md, s_mat, MC, MMD, zg };
+		if (!reg2aln<false, FAST, CPLMAX>(a, ar, r, t, m, TCAP, 0, a.alns + t) && l == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = (int)t;
+	}
 }
 
 // tasks whose reference span, backtrack matrix, CIGAR or MD did not fit LDS: the same code on this workgroup's global slab
@@ -823,14 +854,21 @@ int launch_task_fill(const FinLaunch &a, hipStream_t st)
 size_t cigar_big_slab_bytes() { return CG_BIG_Z + CG_BIG_T + 64; }
 
 // the two lists run side by side (st2 forks from st and joins it again): the no-DP tasks wait on memory, the DP tasks compute
+// grid of the DP kernel and the bytes of backtrack slabs it needs (run_final sizes FinLaunch::zslab with it)
+int cigar_dp_grid(int n_dp) { return n_dp < 256 * 28 ? n_dp : 256 * 28; }
+size_t cigar_zslab_bytes(int max_len, int n_dp)
+{
+	return (size_t)cigar_dp_grid(n_dp) * cigar_zslab_words(max_len < 64 * 3 ? CG_TCAP_SMALL : CG_MAXT) * 4;
+}
 int launch_cigar(const FinLaunch &a, int n_fast, int n_dp, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
 {
 	const bool both = n_fast > 0 && n_dp > 0;
 	if (both && (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess)) return BWAHIP_ENODEV;
 	if (n_dp > 0) {                                             // query columns of the longest read over 64 lanes
-		if (max_len < 64 * 3) hipLaunchKernelGGL((k_cigar<false, 3>), dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
-		else if (max_len < 64 * 5) hipLaunchKernelGGL((k_cigar<false, 5>), dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
-		else hipLaunchKernelGGL((k_cigar<false, 11>), dim3((unsigned)n_dp), dim3(64), 0, st, a, n_dp);
+		const unsigned grid = (unsigned)cigar_dp_grid(n_dp);
+		if (max_len < 64 * 3) hipLaunchKernelGGL((k_cigar<false, 3>), dim3(grid), dim3(64), 0, st, a, n_dp);
+		else if (max_len < 64 * 5) hipLaunchKernelGGL((k_cigar<false, 5>), dim3(grid), dim3(64), 0, st, a, n_dp);
+		else hipLaunchKernelGGL((k_cigar<false, 11>), dim3(grid), dim3(64), 0, st, a, n_dp);
 	}
 	if (n_fast > 0) hipLaunchKernelGGL((k_cigar<true, 1>), dim3((unsigned)n_fast), dim3(64), 0, both ? st2 : st, a, n_fast);
 	if (both && (hipEventRecord(join, st2) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess)) return BWAHIP_ENODEV;

@@ -182,16 +182,31 @@ struct MsLds {
 	uint16_t *cm;                                                // column maxima (tw_cap entries) in LDS for the same reason
 };
 
+// A region list the helpers below may index with offsets the compiler folds into the instruction (&L[i - 1] as base, +80 as offset): with a
+// generic pointer the hardware picks LDS or global from the BASE register alone, and a base one record in front of an LDS array lies
+// outside the LDS aperture -- a memory violation (round 2).  The helpers therefore take a ListRef, and a ListRef into LDS can only be
+// made from a GuardedLds, whose first and last records are never handed out: whatever offset within one record gets folded, the base stays in LDS.
+template <int N> struct __attribute__((aligned(16))) GuardedLds { DevReg g[N + 2]; };
+class ListRef {
+	DevReg *p_;
+	explicit __device__ ListRef(DevReg *p) : p_(p) {}
+public:
+	template <int N> static __device__ __forceinline__ ListRef lds(GuardedLds<N> &a) { return ListRef(a.g + 1); }
+	static __device__ __forceinline__ ListRef global(DevReg *q) { return ListRef(q); }
+	__device__ __forceinline__ DevReg &operator[](int i) const { return p_[i]; }
+	__device__ __forceinline__ DevReg *ptr() const { return p_; }
+};
+
 // mem_sort_dedup_patch with bns == 0 (no patching), as mem_matesw calls it (bwamem_pair.c:203; bwamem.c:444-496).
 // L: the list (n entries), tmp: a spare list of the same capacity, keys / idx: sort scratch (n and 2n entries).
-__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg *L, DevReg *tmp, RegKey *keys, int *idx, int *stk, unsigned *lds256, int l, int *err)
+__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, const ListRef L, const ListRef tmp, RegKey *keys, int *idx, int *stk, unsigned *lds256, int l, int *err)
 {
 	if (n <= 1) return n;
 	for (int i = l; i < n; i += 64) { keys[i].k64 = L[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 	wsync();
 	// the whole wavefront sorts, exactly also when keys are equal (a rescued hit that repeats one of the list: the usual case here); its
 	// scratch is the spare list, which is free while a sort runs
-	if (!wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(tmp), stk, lds256, l)) {
+	if (!wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(tmp.ptr()), stk, lds256, l)) {
 		wsync();
 		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, stk, &bad); if (bad) atomicExch(err, 40 + bad); }
 	}
@@ -235,7 +250,7 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 	n = m;
 	for (int i = l; i < n; i += 64) { L[i] = tmp[i]; keys[i].k64 = tmp[i].rb; keys[i].score = tmp[i].score; keys[i].qb = tmp[i].qb; idx[i] = i; }
 	wsync();
-	if (!wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(tmp), stk, lds256, l)) {
+	if (!wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(tmp.ptr()), stk, lds256, l)) {
 		wsync();
 		if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, stk, &bad); if (bad) atomicExch(err, 50 + bad); }
 	}
@@ -258,7 +273,7 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, DevReg
 // mem_matesw (bwamem_pair.c:137-206): anchor `an` (a region of one end), mate read r_m (length l_ms), mate list L (n_ma).
 // P = 16: byte kernel (l_ms * a < 250), P = 8: word kernel.  Returns the new length of the mate list.
 template <int P>
-__device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int slot0, int r_m, int l_ms, DevReg *L, int n_ma, DevReg *tmp, RegKey *keys, int *idx,
+__device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int slot0, int r_m, int l_ms, const ListRef L, int n_ma, const ListRef tmp, RegKey *keys, int *idx,
                       const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new, unsigned long long &n_inline)
 {
 	const DevOpt &opt = a.opt;
@@ -404,10 +419,9 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 	__shared__ uint8_t s_tw[4096];
 	__shared__ uint16_t s_cm[4096];
 	// 16-byte aligned: the lists are reached through generic pointers (LDS or global slots), i.e. flat 16-byte accesses
-	__shared__ __attribute__((aligned(16))) DevReg s_list_g[MS_LIST + 2];   // one spare record in front and behind (folded address offsets stay inside LDS)
-	__shared__ __attribute__((aligned(16))) DevReg s_tmp_g[MS_LIST + 2];
+	__shared__ GuardedLds<MS_LIST> s_list_g, s_tmp_g;          // (a spare record in front and behind: see ListRef)
 	__shared__ __attribute__((aligned(16))) RegKey s_keys[MS_LIST];
-	DevReg *const s_list = s_list_g + 1, *const s_tmp = s_tmp_g + 1;
+	const ListRef s_list = ListRef::lds(s_list_g), s_tmp = ListRef::lds(s_tmp_g);
 	__shared__ int s_idx[2 * MS_LIST];
 	const int l = lane();
 	if (l < 25) s_mat[l] = a.opt.mat[l];
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 				int *idx = a.pe_idx + 2 * a.pe_base[rm];
 				const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk, s_tw, 4096, s_cm };
 				for (int j = 0; j < a.nb[r]; ++j)
-					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, G, n_list[i ^ 1], tmp, keys, idx, m, slab, l, n_sw, n_new, n_inline);
+					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, ListRef::global(G), n_list[i ^ 1], ListRef::global(tmp), keys, idx, m, slab, l, n_sw, n_new, n_inline);
 			}
 			if (in_lds) { wsync(); for (int k = l; k < n_list[i ^ 1]; k += 64) G[k] = s_list[k]; wsync(); }
 		}

@@ -306,10 +306,10 @@ void bwahip_destroy(bwahip_ctx *c)
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
-	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t, &c->d_dedup,
+	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t, &c->d_dedup, &c->d_cperm,
 	                   &c->d_ctg_names, &c->d_ctg_name_off, &c->d_ctg_anno, &c->d_ctg_anno_off, &c->d_rg, &c->d_qual, &c->d_qual_off, &c->d_names, &c->d_name_off, &c->d_comments, &c->d_comment_off,
 	                   &c->d_fregs, &c->d_fregs2, &c->d_fscr, &c->d_need, &c->d_xa_owner, &c->d_freg_n, &c->d_npri, &c->d_task_n, &c->d_rec_n, &c->d_task_base, &c->d_tasks, &c->d_aln_of_reg, &c->d_alns,
-	                   &c->d_resc_flag, &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
+	                   &c->d_resc_flag, &c->d_zslab, &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
 	                   &c->d_hist, &c->d_pair_tab, &c->d_nb, &c->d_pe_cap, &c->d_pe_base, &c->d_pe_regs, &c->d_pe_n, &c->d_pe_tmp, &c->d_pe_keys, &c->d_pe_idx, &c->d_resc, &c->d_ms_slab, &c->d_pe_read, &c->d_sw_cnt, &c->d_sw_base, &c->d_sw_res, &c->d_sw_tasks, &c->d_sw_info, &c->d_task_lists };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();
@@ -592,9 +592,9 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		cl.flt = c->d_flt.as<int>(); cl.heavy_list = c->d_heavy.as<int>() + 4; cl.heavy_count = c->d_heavy.as<int>();
 		const int big_min = c->knobs.chain_big_min;              // seeds; < 0 = off
 		if (big_min >= 0) {
-			if ((rc = c->d_chain_big.ensure((size_t)(n + 4) * 4))) return rc;
-			HIP_TRY(hipMemsetAsync(c->d_chain_big.p, 0, 16, c->stream));
-			cl.big_list = c->d_chain_big.as<int>() + 4; cl.big_count = c->d_chain_big.as<int>(); cl.big_min = big_min; cl.big_max = 3200;   // 800 LDS nodes >= 0.24 x seeds (every node but the root holds >= 5 keys)
+			if ((rc = c->d_chain_big.ensure(((size_t)4 * n + 8) * 4))) return rc;
+			HIP_TRY(hipMemsetAsync(c->d_chain_big.p, 0, 32, c->stream));
+			cl.big_list = c->d_chain_big.as<int>() + 8; cl.big_count = c->d_chain_big.as<int>(); cl.big_min = big_min; cl.big_max = 3200;   // 800 LDS nodes >= 0.24 x seeds (every node but the root holds >= 5 keys)
 		}
 		HIP_TRY(hipMemsetAsync(c->d_heavy.p, 0, 16, c->stream));
 		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }

@@ -97,35 +97,68 @@ extern "C" int bwahip_stream_run(bwahip_ctx *const *ctxs, int n_ctx, const bwahi
 	d.t_last_write = t_start;
 	std::vector<double> wait_s(n_ctx, 0.), busy_s(n_ctx, 0.);
 	const int keep_comments = st->keep_comments;
+	// Every context has a runner (bwahip_process_seqs_text, batch after batch) and a fetcher that takes the runner's NEXT batch from the
+	// reader meanwhile -- linking a million records into a bseq1_t array, and waiting for the parser, are host work that would otherwise
+	// sit between two batches of the context.
+	struct Slot {
+		std::mutex mu; std::condition_variable cv;
+		bool full = false, eof = false;
+		bwahip_fastq_batch *b = nullptr; bwahip_seq_t *seqs = nullptr; int n = 0; int64_t seq_no = 0, np0 = 0;
+	};
+	std::vector<Slot> slots(n_ctx);
+	auto fetcher = [&](int w) {
+		Slot &sl = slots[w];
+		for (;;) {
+			{ std::unique_lock<std::mutex> lk(sl.mu); sl.cv.wait(lk, [&] { return !sl.full; }); }
+			bwahip_fastq_batch *b = nullptr; bwahip_seq_t *seqs = nullptr; int n = 0;
+			int64_t seq_no = 0, np0 = 0;
+			bool eof = d.failed();
+			const double t0 = now_s();
+			if (!eof) {
+				std::lock_guard<std::mutex> lk(d.mu_read);
+				if (d.eof || (d.max_reads > 0 && d.n_processed >= d.max_reads)) { d.eof = true; eof = true; }
+				else {
+					const int r = bwahip_fastq_next_batch(d.rd, chunk, keep_comments, &b, &seqs, &n);
+					if (r) { d.eof = true; eof = true; d.fail(r); }
+					else if (n == 0) { d.eof = true; eof = true; }
+					else { seq_no = d.next_seq++; np0 = d.n_processed; d.n_processed += n; }
+				}
+			}
+			wait_s[w] += now_s() - t0;
+			{ std::lock_guard<std::mutex> lk(sl.mu); sl.b = b; sl.seqs = seqs; sl.n = n; sl.seq_no = seq_no; sl.np0 = np0; sl.eof = eof; sl.full = true; }
+			sl.cv.notify_all();
+			if (eof) return;
+		}
+	};
 	auto worker = [&](int w) {
+		Slot &sl = slots[w];
+		std::thread ft(fetcher, w);
 		int64_t mine[2] = { -1, -1 };                             // the batches whose text sits in this context's two buffers
 		for (int k = 0;; ++k) {
-			if (d.failed()) break;
-			bwahip_fastq_batch *b = nullptr; bwahip_seq_t *seqs = nullptr; int n = 0;
-			int64_t seq_no, np0;
-			const double t0 = now_s();
+			bwahip_fastq_batch *b; bwahip_seq_t *seqs; int n; int64_t seq_no, np0; bool eof;
 			{
-				std::lock_guard<std::mutex> lk(d.mu_read);
-				if (d.eof) break;
-				if (d.max_reads > 0 && d.n_processed >= d.max_reads) { d.eof = true; break; }
-				const int r = bwahip_fastq_next_batch(d.rd, chunk, keep_comments, &b, &seqs, &n);
-				if (r) { d.eof = true; d.fail(r); break; }
-				if (n == 0) { d.eof = true; break; }
-				seq_no = d.next_seq++; np0 = d.n_processed; d.n_processed += n;
+				std::unique_lock<std::mutex> lk(sl.mu);
+				sl.cv.wait(lk, [&] { return sl.full; });
+				b = sl.b; seqs = sl.seqs; n = sl.n; seq_no = sl.seq_no; np0 = sl.np0; eof = sl.eof;
+				sl.full = false;
 			}
-			const double t1 = now_s();
-			wait_s[w] += t1 - t0;
+			sl.cv.notify_all();
+			if (eof) break;
+			bool stop = d.failed();
 			// this call overwrites the buffer of this context's last-but-one batch: that one must be on the descriptor
-			if (mine[k & 1] >= 0) { std::unique_lock<std::mutex> lk(d.mu); d.cv_done.wait(lk, [&] { return d.rc || d.written > mine[k & 1]; }); if (d.rc) { bwahip_fastq_batch_release(b); break; } }
+			if (!stop && mine[k & 1] >= 0) { std::unique_lock<std::mutex> lk(d.mu); d.cv_done.wait(lk, [&] { return d.rc || d.written > mine[k & 1]; }); stop = d.rc != 0; }
+			if (stop) { bwahip_fastq_batch_release(b); continue; }   // (drain what the fetcher still delivers; it stops at the failure flag)
+			const double t1 = now_s();
 			const char *sam = nullptr; int64_t len = 0;
 			const int r = bwahip_process_seqs_text(ctxs[w], &o, np0, n, seqs, pes0, &sam, &len, nullptr);
 			bwahip_fastq_batch_release(b);                          // names, bases and qualities were staged inside the call
 			busy_s[w] += now_s() - t1;
-			if (r) { d.fail(r); break; }
+			if (r) { d.fail(r); continue; }
 			mine[k & 1] = seq_no;
 			{ std::lock_guard<std::mutex> lk(d.mu); d.ready[seq_no] = { sam, len }; }
 			d.cv_item.notify_all();
 		}
+		ft.join();
 		// the buffers must outlive their write
 		{ std::unique_lock<std::mutex> lk(d.mu); d.cv_done.wait(lk, [&] { return d.rc || (d.written > mine[0] && d.written > mine[1]); }); --d.workers_left; }
 		d.cv_item.notify_all();
