@@ -169,7 +169,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file stream (value falls back to gpu_pipeline)")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("BWAHIP_BENCH_OVERLAP", "2")),
-                    help="contexts per GPU taking the batches in turn (double buffering); 1 = one batch at a time only")
+                    help="contexts per GPU taking the batches in turn (double buffering) in gpu_pipeline; 1 = one batch at a time only")
+    ap.add_argument("--stream-contexts", type=int, default=int(os.environ.get("BWAHIP_BENCH_STREAM_CONTEXTS", "3")),
+                    help="contexts per GPU bwahip_stream_run deals the batches to (file to file: a third context covers the others' host phases)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -298,8 +300,9 @@ def main():
     single = {"value": round(args.reads * world * args.steps / elapsed, 1), "unit": "reads/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps,
               "what": "reads resident in HBM, SAM left in HBM, one batch at a time on one context: the timed region `kernel_ms` and `roofline` are measured in"}
     # ---------------- gpu_pipeline: the same steps double buffered on --overlap contexts sharing the index
-    clones = [ctx.clone() for _ in range(args.overlap - 1)] if args.overlap > 1 else []
-    ctxs = [ctx] + clones
+    clones = [ctx.clone() for _ in range(max(args.overlap, 1 if args.no_e2e else args.stream_contexts) - 1)]
+    ctxs = [ctx] + clones[:max(0, args.overlap - 1)]
+    sctxs = [ctx] + clones[:max(0, args.stream_contexts - 1)]
     dbuf = None
     if len(ctxs) > 1 and n_batches > 1:
         for _ in range(max(1, min(args.warmup, 2))):
@@ -333,29 +336,29 @@ def main():
         # untimed pass 0: SAM to a file on tmpfs (kept for the parity check below); buffers grow to the batch size here
         fd = os.open(stream_sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
-            st0 = bw.stream_run(ctxs, fqs[0], fq2, fd, opt, chunk_bases=K_bases, reader_threads=reader_threads)
+            st0 = bw.stream_run(sctxs, fqs[0], fq2, fd, opt, chunk_bases=K_bases, reader_threads=reader_threads)
         finally:
             os.close(fd)
         log(f"stream pass 0 (to a tmpfs file, buffers growing): {st0.n_reads} reads, {st0.sam_bytes} SAM bytes in {st0.seconds:.3f}s")
         devnull = os.open("/dev/null", os.O_WRONLY)
         for _ in range(max(0, args.warmup - 1)):
-            bw.stream_run(ctxs, fqs[0], fq2, devnull, opt, chunk_bases=K_bases, reader_threads=reader_threads)
+            bw.stream_run(sctxs, fqs[0], fq2, devnull, opt, chunk_bases=K_bases, reader_threads=reader_threads)
         sync_all()
         t0 = time.time()
-        sts = [bw.stream_run(ctxs, fqs[0], fq2, devnull, opt, chunk_bases=K_bases, reader_threads=reader_threads) for _ in range(args.steps)]
+        sts = [bw.stream_run(sctxs, fqs[0], fq2, devnull, opt, chunk_bases=K_bases, reader_threads=reader_threads) for _ in range(args.steps)]
         sync_all()
         el3 = max_over_ranks(time.time() - t0)
         os.close(devnull)
         # the same once more with the SAM written to a tmpfs file (one memcpy of 420 bytes per read more, on the writer thread)
         fd = os.open(stream_sam_path + ".2", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
-            st_file = bw.stream_run(ctxs, fqs[0], fq2, fd, opt, chunk_bases=K_bases, reader_threads=reader_threads)
+            st_file = bw.stream_run(sctxs, fqs[0], fq2, fd, opt, chunk_bases=K_bases, reader_threads=reader_threads)
         finally:
             os.close(fd)
             os.unlink(stream_sam_path + ".2")
         assert all(s.n_reads == args.reads and s.sam_bytes == st0.sam_bytes for s in sts + [st_file])
         stream = {"value": round(args.reads * world * args.steps / el3, 1), "unit": "reads/s", "ms_per_step": round(el3 / args.steps * 1e3, 3),
-                  "contexts_per_gpu": len(ctxs), "reader_threads": reader_threads, "host_threads_per_gpu": opt.n_threads,
+                  "contexts_per_gpu": len(sctxs), "reader_threads": reader_threads, "host_threads_per_gpu": opt.n_threads,
                   "sam_bytes_per_step": int(st0.sam_bytes), "batches_per_step": int(st0.n_batches),
                   "seconds_inside_driver": [round(s.seconds, 4) for s in sts],
                   "workers_waiting_for_reader_s": round(sum(s.reader_wait_s for s in sts) / args.steps, 4),

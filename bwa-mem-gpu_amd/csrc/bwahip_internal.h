@@ -175,12 +175,13 @@ struct ExtLaunch {
 	DevReg *spec_regs; int2 *spec_items; int *spec_n; int spec_min_chains;
 	int rank_sort_min;                           // dedup: lists at least this long try the wavefront rank sort first (shorter: one-lane introsort hides behind other wavefronts)
 	int *redo_list, *redo_n;                     // reads k_extend hands to k_extend_big (reference window beyond the LDS window)
-	int *dedup_list, *dedup_n;                   // reads k_extend leaves with more than one region: k_dedup sorts / dedups / patches them
+	int *dedup_list, *dedup_n;                   // reads k_extend leaves with more than one region: k_dedup sorts / dedups / patches them (two lists of n_reads: [0] the bulk, [1] the heavy reads)
+	int subset;                                  // k_extend / k_dedup: 0 all reads, 1 the heavy ones (first two classes of the launch order), 2 the others
 	uint8_t *big_t;                              // BWAHIP_EXT_BIG_GRID slabs of BWAHIP_EXT_BIG_T + 64 bytes
 	int lds_window;                              // largest reference window k_extend keeps in LDS (<= its compiled MAXT)
 };
 constexpr int BWAHIP_EXT_BIG_GRID = 128, BWAHIP_EXT_BIG_T = 1 << 16;
-int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st);
+int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join);
 int launch_order(int n, const int *keys, int t0, int t1, int t2, int *perm, int *counts, hipStream_t st);   // launch order by classes of keys[r], heaviest first
 int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st);
 

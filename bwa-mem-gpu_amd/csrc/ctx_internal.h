@@ -44,7 +44,7 @@ struct HostBuf {
 struct Knobs {
 	int intv_cap = 96;          // BWAHIP_INTV_CAP: initial per-read interval capacity (grown on overflow)
 	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
-	int heavy_mult = 10;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never)
+	int heavy_mult = -1;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never; -1: 10 for reads up to 200 bases, 30 above -- a 250 bp read at 5 % error needs 2 500 extends on average, and the hand-off is for the outliers)
 	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which a wavefront-per-read chaining kernel takes the read (< 0: off)
 	int rank_sort_min = 2;      // BWAHIP_RANK_SORT_MIN: dedup lists at least this long are sorted by the whole wavefront (shorter: the one-lane restatement of ks_introsort)
 	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)

@@ -266,22 +266,35 @@ __device__ __forceinline__ int pair_extend_c(const DevIndex &ix, const Bi &ik, i
 }
 
 // One LF step (bwt.c:53 bwt_invPsi) by ONE lane: the lane reads the whole 64-byte block of k.
-__device__ __forceinline__ uint64_t lane_lf(const DevIndex &ix, uint64_t k)
+// lane_lf in two halves -- the block fetch and the count -- so that a lane walking several rows at once (k_seed_walk) has all its fetches
+// in flight before it waits for the first
+struct LfBlock { uint4 v0, v1, v2, v3; };
+__device__ __forceinline__ void lane_lf_fetch(const DevIndex &ix, uint64_t k, LfBlock &f)
 {
 	const uint64_t pp = k - (k >= ix.primary);
 	const uint4 *b = ix.bwt + (pp >> 7) * 4;
+	f.v3 = make_uint4(0, 0, 0, 0);
+	f.v0 = b[0]; f.v1 = b[1]; f.v2 = b[2];
+	if ((pp & 127) >= 64) f.v3 = b[3];                       // the second 64 bases only when the position lies there (k_seed_walk 8.3 -> 8.0 ms)
+}
+__device__ __forceinline__ uint64_t lane_lf_count(const DevIndex &ix, uint64_t k, const LfBlock &f)
+{
+	const uint64_t pp = k - (k >= ix.primary);
 	const int o = (int)(pp & 127);
-	uint4 v3 = make_uint4(0, 0, 0, 0);
-	const uint4 v0 = b[0], v1 = b[1], v2 = b[2];
-	if (o >= 64) v3 = b[3];                                  // the second 64 bases only when the position lies there (k_seed_walk 8.3 -> 8.0 ms)
-	const uint4 h = o < 64 ? v2 : v3;
+	const uint4 h = o < 64 ? f.v2 : f.v3;
 	const int wi = o >> 4 & 3;
 	const uint32_t w = wi == 0 ? h.x : wi == 1 ? h.y : wi == 2 ? h.z : h.w;
 	const uint32_t c = w >> ((~o & 15) << 1) & 3;
-	const uint32_t packed = count_bases64(v2, o + 1 < 64 ? o + 1 : 64) + count_bases64(v3, o + 1 > 64 ? o + 1 - 64 : 0);
-	const uint64_t c0 = (uint64_t)v0.y << 32 | v0.x, c1 = (uint64_t)v0.w << 32 | v0.z, c2 = (uint64_t)v1.y << 32 | v1.x, c3 = (uint64_t)v1.w << 32 | v1.z;
+	const uint32_t packed = count_bases64(f.v2, o + 1 < 64 ? o + 1 : 64) + count_bases64(f.v3, o + 1 > 64 ? o + 1 - 64 : 0);
+	const uint64_t c0 = (uint64_t)f.v0.y << 32 | f.v0.x, c1 = (uint64_t)f.v0.w << 32 | f.v0.z, c2 = (uint64_t)f.v1.y << 32 | f.v1.x, c3 = (uint64_t)f.v1.w << 32 | f.v1.z;
 	const uint64_t x = L2_at(ix, (int)c) + sel4((int)c, c0, c1, c2, c3) + (packed >> (c << 3) & 0xff);
 	return k == ix.primary ? 0 : x;
+}
+__device__ __forceinline__ uint64_t lane_lf(const DevIndex &ix, uint64_t k)
+{
+	LfBlock f;
+	lane_lf_fetch(ix, k, f);
+	return lane_lf_count(ix, k, f);
 }
 
 // One LF step (bwt.c:53 bwt_invPsi) by a quad; k uniform inside the quad; all lanes get the result.

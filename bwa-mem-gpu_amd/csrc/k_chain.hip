@@ -377,7 +377,7 @@ __device__ void write_chains(const ReadCtx &c, const DevIndex &ix, int n, const 
 constexpr int BIG_NODES = 800;                               // 800 x 192 B = 150 KB of LDS; nodes <= 0.24 x seeds + a few
 constexpr int MID_NODES = 400, MID_SEEDS = 1536;             // two workgroups per CU for the (far more common) reads up to 1536 seeds
 constexpr int SMALL_NODES = 72, SMALL_SEEDS = 256;           // eleven per CU for reads of a few dozen to 256 seeds (14 KB)
-constexpr int GLB_LDS = 2048;                                // reads beyond big_max seeds: nodes in their global slots, this much LDS for the sort's small tables
+constexpr int GLB_LDS = 2048 + 512;                          // reads beyond big_max seeds: nodes in their global slots, this much LDS for the sort's small tables (+ the unused ends)
 // classes of the wavefront-per-read kernels: 0 = up to SMALL_SEEDS, 1 = up to MID_SEEDS, 2 = up to big_max, 3 = beyond (global nodes)
 __device__ __forceinline__ int coop_class(int S, int big_max) { return S <= SMALL_SEEDS ? 0 : S <= MID_SEEDS ? 1 : S <= big_max ? 2 : 3; }
 
@@ -468,10 +468,12 @@ __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *
 		// included (isort_dev.h); the B-tree is no longer needed, so its LDS (or, for the reads with global nodes, the filter's scratch of
 		// the read, free until the filter) holds the keys, the index array and the sort's tables.  The one-lane restatement takes over only
 		// at the introsort's depth limit.
-		uint8_t *area = lds_nodes ? lds_area : reinterpret_cast<uint8_t*>(a.flt + 8 * sb);
-		const size_t area_bytes = lds_nodes ? (size_t)lds_bytes : (size_t)S * 32;
+		// (LDS is reached through generic pointers here: 256 bytes at either end of the array are left alone, so that no folded offset
+		// can put a base register outside the LDS aperture -- DESIGN 4.2)
+		uint8_t *area = lds_nodes ? lds_area + 256 : reinterpret_cast<uint8_t*>(a.flt + 8 * sb);
+		const size_t area_bytes = lds_nodes ? (size_t)lds_bytes - 512 : (size_t)S * 32;
 		// layout: keys[n] (16 B) | idx[n] | work (8-byte aligned) ; the stack and the 256-word table always in LDS
-		int *stk = reinterpret_cast<int*>(lds_nodes ? lds_area + lds_bytes - 2048 : lds_area);
+		int *stk = reinterpret_cast<int*>(lds_nodes ? lds_area + lds_bytes - 256 - 2048 : lds_area + 256);
 		unsigned *tab = reinterpret_cast<unsigned*>(stk + 256);
 		const size_t need = (size_t)n_chn * 20 + 8 + wv::ws_work_ints(n_chn) * 4 + (lds_nodes ? 2048 : 0);
 		bool sorted = false;

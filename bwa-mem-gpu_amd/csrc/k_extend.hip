@@ -582,7 +582,8 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
-	__shared__ unsigned s_he[WIN_MAX];
+	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
+	unsigned *const s_he = s_he_g + 64;
 	const int l = lane();
 	const DevOpt &opt = a.opt;
 	const DevIndex &ix = a.ix;
@@ -652,6 +653,7 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 	const int64_t l_pac = ix.l_pac;
 	const bool use_spec = !BIGT && a.spec_regs && n_chains >= a.spec_min_chains;
 	DevReg *av = a.regs + rb0;                                  // the read's region list (av of bwamem.c:639)
+	DevReg *const gav = av;
 	int *srt = a.srt + 2 * sb;                                  // [0..n): seed index in ascending (score,idx) order; [n..2n): skipped flag
 	int n_av = 0;
 	Work wk = { 0, 0, 0 };
@@ -660,7 +662,8 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 	__syncthreads();
 	if (l < 25) s_mat[l] = opt.mat[l];
 	sw.mx = wmax(l < 25 ? (int)opt.mat[l] : 0); if (sw.mx < 0) sw.mx = 0;
-	for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
+	bool have_q = PHASE != 2;                                   // the dedup pass needs the query only for mem_patch_reg's alignment (rare): fetched then
+	if (have_q) for (int i = l; i < l_query; i += 64) s_q[i] = query[i];
 	__syncthreads();
 
 	if (PHASE == 2) n_av = a.reg_n[r];
@@ -773,7 +776,8 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 	if (PHASE == 1 && n_av > 1) {                               // the list goes on to k_dedup
 		if (l == 0) {
 			a.reg_n[r] = n_av;
-			a.dedup_list[atomicAdd(a.dedup_n, 1)] = r;
+			const int li = a.subset == 1 ? 1 : 0;                   // the heavy reads' list is the second one
+			a.dedup_list[(size_t)li * a.n_reads + atomicAdd(&a.dedup_n[li], 1)] = r;
 			if (wk.cells) { atomicAdd(&cnt_row(a.counters)[CNT_CELLS], wk.cells); atomicAdd(&cnt_row(a.counters)[CNT_ROWS1], (unsigned long long)wk.rows1); atomicAdd(&cnt_row(a.counters)[CNT_ROWSN], (unsigned long long)wk.rowsN); }
 			atomicMax(&cnt_row(a.counters)[14], t_1 - t_0);
 		}
@@ -784,24 +788,37 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 	// collective.  The sort permutes an index array; the list is then gathered into that order.
 	int n = n_av;
 	unsigned long long t_s1 = t_1, t_lp = t_1;
+	// k_dedup, lists of up to 32 regions (nearly all): the list, its spare copy, the keys and the index array live in LDS for the whole
+	// pass -- some fifteen dependent round trips per read otherwise go to global memory -- and the result is written back once
+	constexpr int STAGE_N = 32;
+	const bool stage = PHASE == 2 && s_v != nullptr && v_cap >= 2048 && n > 1 && n <= STAGE_N;
+	DevReg *tmpv = a.tmp_regs + rb0;
+	RegKey *keys = reinterpret_cast<RegKey*>(tmpv);             // (global form: the spare list is free whenever a sort runs)
+	int *idx = srt;                                             // needs n ints (n <= number of seeds)
+	int *work_lds = nullptr;
+	if (stage) {
+		uint8_t *L = reinterpret_cast<uint8_t*>(s_v);
+		for (int i = l; i < n * 5; i += 64) reinterpret_cast<uint4*>(L)[i] = reinterpret_cast<const uint4*>(gav)[i];
+		av = reinterpret_cast<DevReg*>(L); tmpv = reinterpret_cast<DevReg*>(L + STAGE_N * 80); keys = reinterpret_cast<RegKey*>(L + 2 * STAGE_N * 80);
+		idx = reinterpret_cast<int*>(L + 2 * STAGE_N * 80 + STAGE_N * 16); work_lds = idx + 2 * STAGE_N;
+		__threadfence_block(); __syncthreads();
+	}
 	if (n > 1) {
-		int *idx = srt;                                         // reuse: needs n ints (n <= number of seeds)
 		// sort by re
-		RegKey *keys = reinterpret_cast<RegKey*>(a.tmp_regs + rb0);   // the spare list is free until the gather below
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
 		// ks_introsort(mem_ars2): by the whole wavefront, exact also with equal keys (regsort_dev.h / isort_dev.h); the one-lane restatement
 		// only when the introsort's depth limit is reached (or the test knob asks for it).  Scratch: behind the keys in the spare list.
-		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 0}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l, s_v, v_cap)) {
+		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 0}, n, idx, stage ? work_lds : reinterpret_cast<int*>(keys + n), s_stk, s_he, l, stage ? nullptr : s_v, stage ? 0 : v_cap)) {
 			__threadfence_block(); __syncthreads();
 			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 0}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 10 + bad); }
 		}
 		__threadfence_block(); __syncthreads();
 		t_s1 = wall_clock64();
 		// gather into sorted order through the spare list (all lanes), then copy back
-		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
+		for (int i = l; i < n; i += 64) tmpv[i] = av[idx[i]];
 		__threadfence_block(); __syncthreads();
-		for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+		for (int i = l; i < n; i += 64) av[i] = tmpv[i];
 		__threadfence_block(); __syncthreads();
 		if (l == 0) for (int i = 0; i < n; ++i) av[i].n_comp = 1;
 		__threadfence_block(); __syncthreads();
@@ -865,6 +882,7 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 								}
 							if (have) {
 								__syncthreads();
+								if (!have_q) { for (int t = l; t < l_query; t += 64) s_q[t] = query[t]; have_q = true; }
 								for (int t = l; t < rlen; t += 64) s_t[t] = (uint8_t)ref_base(ix, grb + t);
 								__syncthreads();
 								const bool rev = grb >= l_pac;      // both reversed so gaps are left-aligned on the forward strand (bwa.c:275-280)
@@ -927,24 +945,24 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 				const int i = base + l;
 				const bool keep = i < n && av[i].qe > av[i].qb;
 				const unsigned long long km = __ballot(keep);
-				if (keep) a.tmp_regs[rb0 + m + __popcll(km & ((1ull << l) - 1))] = av[i];
+				if (keep) tmpv[m + __popcll(km & ((1ull << l) - 1))] = av[i];
 				m += __popcll(km);
 			}
 			__threadfence_block(); __syncthreads();
 			n = m;
-			for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+			for (int i = l; i < n; i += 64) av[i] = tmpv[i];
 			__threadfence_block(); __syncthreads();
 		}
 		for (int i = l; i < n; i += 64) { keys[i].k64 = av[i].rb; keys[i].score = av[i].score; keys[i].qb = av[i].qb; idx[i] = i; }
 		__threadfence_block(); __syncthreads();
-		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 1}, n, idx, reinterpret_cast<int*>(keys + n), s_stk, s_he, l, s_v, v_cap)) {
+		if (n < a.rank_sort_min || !wave_sort_exact(RegSort{keys, 1}, n, idx, stage ? work_lds : reinterpret_cast<int*>(keys + n), s_stk, s_he, l, stage ? nullptr : s_v, stage ? 0 : v_cap)) {
 			__threadfence_block(); __syncthreads();
 			if (l == 0) { int bad = 0; rs_introsort(RegSort{keys, 1}, n, idx, s_stk, &bad); if (bad) atomicExch(a.err, 20 + bad); }
 		}
 		__threadfence_block(); __syncthreads();
-		for (int i = l; i < n; i += 64) a.tmp_regs[rb0 + i] = av[idx[i]];
+		for (int i = l; i < n; i += 64) tmpv[i] = av[idx[i]];
 		__threadfence_block(); __syncthreads();
-		for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+		for (int i = l; i < n; i += 64) av[i] = tmpv[i];
 		__threadfence_block(); __syncthreads();
 		{                                                       // identical hits (same score, rb, qb as the predecessor) go; bwamem.c:488-494
 			int m = 0;
@@ -953,17 +971,21 @@ __device__ __forceinline__ void extend_read(const ExtLaunch &a, const int r, uin
 				bool keep = i < n;
 				if (i > 0 && i < n) keep = !(av[i].score == av[i-1].score && av[i].rb == av[i-1].rb && av[i].qb == av[i-1].qb);
 				const unsigned long long km = __ballot(keep);
-				if (keep) a.tmp_regs[rb0 + m + __popcll(km & ((1ull << l) - 1))] = av[i];
+				if (keep) tmpv[m + __popcll(km & ((1ull << l) - 1))] = av[i];
 				m += __popcll(km);
 			}
 			__threadfence_block(); __syncthreads();
 			n = m;
-			for (int i = l; i < n; i += 64) av[i] = a.tmp_regs[rb0 + i];
+			for (int i = l; i < n; i += 64) av[i] = tmpv[i];
 			__threadfence_block(); __syncthreads();
 		}
 	}
 	for (int i = l; i < n; i += 64) {                           // bwamem.c:1091-1095
 		if (av[i].rid >= 0 && ix.anns[av[i].rid].is_alt) av[i].is_alt = 1;
+	}
+	if (stage) {                                                // the finished list back to its global slots
+		__threadfence_block(); __syncthreads();
+		for (int i = l; i < n * 5; i += 64) reinterpret_cast<uint4*>(gav)[i] = reinterpret_cast<const uint4*>(av)[i];
 	}
 	if (l == 0) {
 		a.reg_n[r] = n;
@@ -981,9 +1003,19 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
-	__shared__ int s_stk[3 * 80];
-	__shared__ unsigned s_he[WIN_MAX];
-	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;   // heavy reads are scheduled first (k_order)
+	__shared__ int s_stk_g[3 * 80 + 32];
+	int *const s_stk = s_stk_g + 16;
+	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
+	unsigned *const s_he = s_he_g + 64;
+	// a.subset 1: the reads with many seeds left (the first two classes of the launch order), on their own stream with their own k_dedup behind
+	// them, so that their long extensions AND their long lists run beside the bulk; 2: all other reads; 0: everything (no launch order)
+	const int n_heavy = a.perm ? a.perm_counts[0] + a.perm_counts[1] : 0;
+	if (a.subset == 1) {
+		for (int idx = (int)blockIdx.x; idx < n_heavy; idx += (int)gridDim.x) { extend_read<CPL, false, 1>(a, a.perm[idx], s_q, s_t, s_mat, s_stk, s_he); __syncthreads(); }
+		return;
+	}
+	if (a.subset == 2 && (int)blockIdx.x < n_heavy) return;
+	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
 	extend_read<CPL, false, 1>(a, r, s_q, s_t, s_mat, s_stk, s_he);
 }
 
@@ -994,12 +1026,19 @@ __global__ __launch_bounds__(64) void k_dedup(ExtLaunch a)
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
-	__shared__ int s_stk[3 * 80];
-	__shared__ unsigned s_he[WIN_MAX];
-	__shared__ unsigned s_v[2048];                              // the sort's working array for lists up to 2048 regions (longer ones: global memory)
-	const int n_list = *a.dedup_n;
+	__shared__ int s_stk_g[3 * 80 + 32];
+	int *const s_stk = s_stk_g + 16;
+	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
+	unsigned *const s_he = s_he_g + 64;
+	// the sort's working array for lists up to 2048 regions (longer ones: global memory); short lists live here whole.  It is reached through
+	// generic pointers, so 256 bytes in front and behind are never handed out: whatever constant offset the compiler folds into a flat
+	// instruction, its base register stays inside the LDS aperture (the array may well sit at LDS offset 0)
+	__shared__ __attribute__((aligned(16))) unsigned s_v_g[2048 + 128];
+	unsigned *const s_v = s_v_g + 64;
+	const int li = a.subset == 1 ? 1 : 0;
+	const int n_list = a.dedup_n[li];
 	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
-		extend_read<CPL, false, 2>(a, a.dedup_list[n_list - 1 - it], s_q, s_t, s_mat, s_stk, s_he, s_v, 2048);   // from the end of the list: the reads k_extend finished last are the ones with the longest lists
+		extend_read<CPL, false, 2>(a, a.dedup_list[(size_t)li * a.n_reads + n_list - 1 - it], s_q, s_t, s_mat, s_stk, s_he, s_v, 2048);   // from the end of the list: the reads k_extend finished last are the ones with the longest lists
 		__syncthreads();
 	}
 }
@@ -1010,8 +1049,10 @@ __global__ __launch_bounds__(64) void k_extend_big(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ int8_t s_mat[32];
-	__shared__ int s_stk[3 * 80];
-	__shared__ unsigned s_he[WIN_MAX];
+	__shared__ int s_stk_g[3 * 80 + 32];
+	int *const s_stk = s_stk_g + 16;
+	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
+	unsigned *const s_he = s_he_g + 64;
 	uint8_t *s_t = a.big_t + (size_t)blockIdx.x * (BIG_T + 64);
 	const int n_redo = *a.redo_n;
 	for (int it = (int)blockIdx.x; it < n_redo; it += (int)gridDim.x) {
@@ -1059,7 +1100,8 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
 	__shared__ uint8_t s_q[MAXQ + 8];
 	__shared__ uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
-	__shared__ unsigned s_he[WIN_MAX];
+	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
+	unsigned *const s_he = s_he_g + 64;
 	const int r = blockIdx.x, l = lane();
 	if (r >= n) return;
 	const int *p = params + 10 * r;
@@ -1083,8 +1125,10 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
 // known-answer kernel: the wavefront's exact introsort (regsort_dev.h / isort_dev.h) beside the one-lane restatement of ksort.h on the same keys
 __global__ __launch_bounds__(64) void k_kat_isort(int n, int mode, const RegKey *keys, int *idx_par, int *idx_seq, int *work, int *status)
 {
-	__shared__ int s_stk[3 * 80];
-	__shared__ unsigned s_lds[256];
+	__shared__ int s_stk_g[3 * 80 + 32];
+	int *const s_stk = s_stk_g + 16;
+	__shared__ __attribute__((aligned(16))) unsigned s_lds_g[256 + 128];
+	unsigned *const s_lds = s_lds_g + 64;
 	const int l = lane();
 	for (int i = l; i < n; i += 64) { idx_par[i] = i; idx_seq[i] = i; }
 	__threadfence_block(); __syncthreads();
@@ -1133,23 +1177,32 @@ int launch_extend_spec(const ExtLaunch &a, int max_len, hipStream_t st)
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
-int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st)
+template <int CPL> static void launch_extend_cpl(ExtLaunch a, hipStream_t st, hipStream_t st2)
+{
+	const int dgrid = a.n_reads < 32768 ? a.n_reads : 32768;
+	if (a.perm && st2) {
+		a.subset = 1;                                            // the heavy reads: extension, then their lists, on the second stream
+		hipLaunchKernelGGL(k_extend<CPL>, dim3(a.n_reads < 4096 ? a.n_reads : 4096), dim3(64), 0, st2, a);
+		hipLaunchKernelGGL(k_dedup<CPL>, dim3(a.n_reads < 4096 ? a.n_reads : 4096), dim3(64), 0, st2, a);
+		a.subset = 2;
+	} else a.subset = 0;
+	hipLaunchKernelGGL(k_extend<CPL>, dim3(a.n_reads), dim3(64), 0, st, a);
+	hipLaunchKernelGGL(k_dedup<CPL>, dim3(dgrid), dim3(64), 0, st, a);
+}
+
+// st2 / fork / join: a second stream (and two events) of the context; nullptr = everything on st
+int launch_extend(const ExtLaunch &a, int max_len, hipStream_t st, hipStream_t st2, hipEvent_t fork, hipEvent_t join)
 {
 	if (a.n_reads <= 0) return 0;
-	if (a.perm) {
-		launch_order(a.n_reads, a.kept_seeds, 1024, 256, 64, a.perm, a.perm_counts, st);
-	}
+	if (a.perm) launch_order(a.n_reads, a.kept_seeds, 1024, 256, 64, a.perm, a.perm_counts, st);
+	const bool two = a.perm && st2 && fork && join;
+	if (two && (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess)) return BWAHIP_ENODEV;
 	// columns 0..max_len must fit in 64 lanes x CPL registers
-	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_extend<3>, dim3(a.n_reads), dim3(64), 0, st, a);
-	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_extend<4>, dim3(a.n_reads), dim3(64), 0, st, a);
-	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_extend<5>, dim3(a.n_reads), dim3(64), 0, st, a);
-	else hipLaunchKernelGGL(k_extend<11>, dim3(a.n_reads), dim3(64), 0, st, a);
-	// sort / dedup / patch of the reads left with more than one region
-	const int dgrid = a.n_reads < 32768 ? a.n_reads : 32768;
-	if (max_len + 1 <= 64 * 3) hipLaunchKernelGGL(k_dedup<3>, dim3(dgrid), dim3(64), 0, st, a);
-	else if (max_len + 1 <= 64 * 4) hipLaunchKernelGGL(k_dedup<4>, dim3(dgrid), dim3(64), 0, st, a);
-	else if (max_len + 1 <= 64 * 5) hipLaunchKernelGGL(k_dedup<5>, dim3(dgrid), dim3(64), 0, st, a);
-	else hipLaunchKernelGGL(k_dedup<11>, dim3(dgrid), dim3(64), 0, st, a);
+	if (max_len + 1 <= 64 * 3) launch_extend_cpl<3>(a, st, two ? st2 : nullptr);
+	else if (max_len + 1 <= 64 * 4) launch_extend_cpl<4>(a, st, two ? st2 : nullptr);
+	else if (max_len + 1 <= 64 * 5) launch_extend_cpl<5>(a, st, two ? st2 : nullptr);
+	else launch_extend_cpl<11>(a, st, two ? st2 : nullptr);
+	if (two && (hipEventRecord(join, st2) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess)) return BWAHIP_ENODEV;
 	// reads whose reference window exceeded the LDS window (none on ordinary data): one generic instantiation
 	hipLaunchKernelGGL(k_extend_big<11>, dim3(BWAHIP_EXT_BIG_GRID), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;

@@ -363,7 +363,7 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 			}
 			++n;
 		}
-		if (n) { const unsigned long long tk3 = wall_clock64(); n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, reinterpret_cast<unsigned*>(m.h), l, a.err); if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }
+		if (n) { const unsigned long long tk3 = wall_clock64(); n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, reinterpret_cast<unsigned*>(m.h + 128), l, a.err); if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }   // (m.h + 128: 256 bytes into the array -- a base register of the sort's table accesses stays inside LDS whatever offset gets folded)
 	}
 	return n_ma;
 }

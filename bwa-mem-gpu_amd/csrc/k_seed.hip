@@ -77,29 +77,49 @@ __global__ __launch_bounds__(256) void k_seed_rows(SeedLaunch a)
 // K2b -- bwt_sa (bwt.c:86): one lane per look-up, every lane walking on its own: up to sa_intv-1 dependent LF steps
 // (bwt.c:53), each one whole 64-byte Occ block read by the lane itself, then one 8-byte SA read.  A lane that
 // finishes takes its next slot at once (the row was prefetched), so the wavefront never waits for its slowest walk.
+// W walks per lane.  A walk is a chain of dependent 64-byte gathers, so a lane with one walk has one request in flight; W = 2 issues the
+// second walk's request while the first is on its way.  Measured (3.1 Gbp index, 1 M-read batches, same box, twice): 8.42 ms with one walk,
+// 8.80 ms with two -- 2 048 lanes per CU already keep about two thousand requests in flight, the kernel sits at the request rate of the
+// memory system (scripts/gather_bw.hip), and the second walk only costs registers and issue slots.  W = 1 is what runs; BWAHIP_SEED_WALKS=2 selects the other.
+template <int W>
 __global__ __launch_bounds__(256) void k_seed_walk(SeedLaunch a, long long total)
 {
 	const DevIndex &ix = a.ix;
 	const long long n_lanes = (long long)gridDim.x * blockDim.x;
-	long long next = (long long)blockIdx.x * blockDim.x + threadIdx.x, sid = 0;
+	long long next = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t mask = (uint64_t)ix.sa_intv - 1;
-	uint64_t k = 0, k_pref = next < total ? (uint64_t)a.seeds[next].rbeg : 0;
-	unsigned steps = 0, n_lf = 0, n_sa = 0;
-	bool have = false;
+	uint64_t k_pref = next < total ? (uint64_t)a.seeds[next].rbeg : 0;
+	long long sid[W]; uint64_t k[W]; unsigned steps[W]; bool have[W];
+#pragma unroll
+	for (int w = 0; w < W; ++w) { sid[w] = 0; k[w] = 0; steps[w] = 0; have[w] = false; }
+	unsigned n_lf = 0, n_sa = 0;
 	for (;;) {
-		if (!have && next < total) {
-			sid = next; k = k_pref; steps = 0; have = true;
-			next += n_lanes;
-			if (next < total) k_pref = (uint64_t)a.seeds[next].rbeg;
+		bool any = false;
+#pragma unroll
+		for (int w = 0; w < W; ++w) {
+			if (!have[w] && next < total) {
+				sid[w] = next; k[w] = k_pref; steps[w] = 0; have[w] = true;
+				next += n_lanes;
+				if (next < total) k_pref = (uint64_t)a.seeds[next].rbeg;
+			}
+			any |= have[w];
 		}
-		if (__ballot(have) == 0) break;
-		const bool fin = have && (k & mask) == 0;
-		const bool walk = have && !fin;
-		uint64_t sa_v = 0, nk = 0;                              // each lane issues only the gather it needs (no dummy loads of element 0: -1 %)
-		if (fin) sa_v = ix.sa[k >> ix.sa_shift];
-		if (walk) nk = lane_lf(ix, k);
-		if (fin) { a.seeds[sid].rbeg = (int64_t)(steps + sa_v); have = false; ++n_sa; }
-		if (walk) { n_lf += k != ix.primary; k = nk; ++steps; }
+		if (__ballot(any) == 0) break;
+		uint64_t sa_v[W]; bool fin[W], walk[W]; LfBlock blk[W];
+#pragma unroll
+		for (int w = 0; w < W; ++w) {                            // all gathers of this round are issued before any is used
+			fin[w] = have[w] && (k[w] & mask) == 0;
+			walk[w] = have[w] && !fin[w];
+			sa_v[w] = 0;
+			blk[w].v0 = blk[w].v1 = blk[w].v2 = blk[w].v3 = make_uint4(0, 0, 0, 0);
+			if (fin[w]) sa_v[w] = ix.sa[k[w] >> ix.sa_shift];
+			if (walk[w]) lane_lf_fetch(ix, k[w], blk[w]);
+		}
+#pragma unroll
+		for (int w = 0; w < W; ++w) {
+			if (fin[w]) { a.seeds[sid[w]].rbeg = (int64_t)(steps[w] + sa_v[w]); have[w] = false; ++n_sa; }
+			if (walk[w]) { n_lf += k[w] != ix.primary; k[w] = lane_lf_count(ix, k[w], blk[w]); ++steps[w]; }
+		}
 	}
 	unsigned long long lf = n_lf, sa = n_sa;
 	for (int m = 32; m; m >>= 1) { lf += __shfl_xor(lf, m); sa += __shfl_xor(sa, m); }
@@ -152,7 +172,9 @@ int launch_seeds(const SeedLaunch &a, int64_t total, hipStream_t st)
 	hipLaunchKernelGGL(k_seed_rows, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
 	long long blocks = (total + 255) / 256;
 	if (blocks > 256 * 8) blocks = 256 * 8;                   // 8 waves per SIMD resident; lanes stride over the rest
-	hipLaunchKernelGGL(k_seed_walk, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
+	static const int walks = getenv("BWAHIP_SEED_WALKS") ? atoi(getenv("BWAHIP_SEED_WALKS")) : 1;
+	if (walks >= 2) hipLaunchKernelGGL(k_seed_walk<2>, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
+	else hipLaunchKernelGGL(k_seed_walk<1>, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
 	hipLaunchKernelGGL(k_seed_rid, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, (long long)total);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }

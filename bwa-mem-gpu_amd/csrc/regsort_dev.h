@@ -57,6 +57,31 @@ __device__ __forceinline__ size_t ws_work_ints(int n) { return is_scratch_ints(n
 __device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int *stk, unsigned *lds, int l, unsigned *v_lds = nullptr, int v_cap = 0)
 {
 	if (n > 65535) return false;
+	if (n <= 64) {
+		// short lists (nearly all of them: two or three regions): one key per lane, the others come by shuffle; without ties the count of
+		// smaller keys is the slot and nothing but idx is touched
+		RegKey kt; kt.k64 = 0; kt.score = 0; kt.qb = 0;
+		if (l < n) kt = c.key[l];
+		int cnt = 0; bool tie = false;
+		for (int u = 0; u < n; ++u) {
+			RegKey ku;
+			ku.k64 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)kt.k64, u) | (uint64_t)(uint32_t)__shfl((int)((uint64_t)kt.k64 >> 32), u) << 32);
+			ku.score = __shfl(kt.score, u); ku.qb = __shfl(kt.qb, u);
+			bool lt_ut, eq;
+			if (c.mode == 0) { lt_ut = ku.k64 < kt.k64; eq = ku.k64 == kt.k64; }
+			else {
+				eq = ku.score == kt.score && ku.k64 == kt.k64 && ku.qb == kt.qb;
+				lt_ut = ku.score > kt.score || (ku.score == kt.score && (ku.k64 < kt.k64 || (ku.k64 == kt.k64 && ku.qb < kt.qb)));
+			}
+			cnt += lt_ut ? 1 : 0;
+			tie |= eq && u != l;
+		}
+		if (!__ballot(l < n && tie)) {
+			if (l < n) idx[cnt] = l;
+			is_sync();
+			return true;
+		}
+	}
 	int *qs_scratch = work;
 	unsigned *v = n <= v_cap ? v_lds : reinterpret_cast<unsigned*>(work + is_scratch_ints(n));
 	uint8_t *tied = reinterpret_cast<uint8_t*>(work + is_scratch_ints(n) + n);

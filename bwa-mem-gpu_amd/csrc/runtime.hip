@@ -524,7 +524,7 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		sl.seq4 = c->d_seq4.as<uint64_t>();
 		if (attempt == 0 && (rc = launch_pack4(sl, c->stream))) return rc;
 		sl.scratch = c->d_scratch.as<DevIntv>(); sl.lcap = lcap; sl.queue = queue; sl.counters = counters; sl.err = err; sl.groups_total = groups;
-		const int heavy_mult = c->knobs.heavy_mult;              // x read length; 0 = never hand off
+		const int heavy_mult = c->knobs.heavy_mult >= 0 ? c->knobs.heavy_mult : c->max_len <= 200 ? 10 : 30;   // x read length; 0 = never hand off
 		if ((rc = c->d_smem_heavy.ensure((size_t)n * 4))) return rc;
 		sl.heavy_list = c->d_smem_heavy.as<int>(); sl.heavy_n = queue + 1; sl.heavy_mult = heavy_mult; sl.worst_n = (int*)(queue + 2);
 		if (timed) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -638,7 +638,7 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		el.counters = counters; el.err = err;
 		if ((rc = c->d_redo.ensure((size_t)(n + 4) * 4)) || (rc = c->d_big_t.ensure((size_t)BWAHIP_EXT_BIG_GRID * (BWAHIP_EXT_BIG_T + 64)))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 16, c->stream));
-		if ((rc = c->d_dedup.ensure((size_t)(n + 4) * 4))) return rc;
+		if ((rc = c->d_dedup.ensure(((size_t)2 * n + 4) * 4))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_dedup.p, 0, 16, c->stream));
 		el.dedup_n = c->d_dedup.as<int>(); el.dedup_list = c->d_dedup.as<int>() + 4;
 		el.redo_n = c->d_redo.as<int>(); el.redo_list = c->d_redo.as<int>() + 4; el.big_t = c->d_big_t.as<uint8_t>(); el.lds_window = c->knobs.ext_lds_window;
@@ -654,7 +654,7 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		STAGE_LOG("k_extend_spec");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[8], c->stream));
 		if (verbose) fprintf(stderr, "[bwahip] seeds=%lld regs_cap=%lld\n", (long long)total, (long long)total_regs);
-		if ((rc = launch_extend(el, c->max_len, c->stream))) return rc;
+		if ((rc = launch_extend(el, c->max_len, c->stream, c->stream2, c->ev_fork, c->ev_join))) return rc;
 		STAGE_LOG("k_extend");
 		if (timed) HIP_TRY(hipEventRecord(c->ev[9], c->stream));
 		int h_err2[2] = { 0, 0 };

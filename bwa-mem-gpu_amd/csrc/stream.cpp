@@ -14,6 +14,8 @@
 // context took a batch (tests/test_gpu_multi.py).  No data-path collective: SURVEY.md 8(e).
 #include "../../include/bwahip.h"
 #include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include <chrono>
@@ -75,6 +77,15 @@ struct Driver {
 	}
 };
 
+// Closing the reader (joining its threads, unmapping gigabytes of input: tens of milliseconds of page-table work) is nobody's critical path:
+// it runs on a thread of its own, joined by the next run or when the library is unloaded.
+struct Reaper {
+	std::mutex mu; std::thread t;
+	void close_later(bwahip_fastq *rd) { std::lock_guard<std::mutex> lk(mu); if (t.joinable()) t.join(); t = std::thread([rd] { bwahip_fastq_close(rd); }); }
+	~Reaper() { if (t.joinable()) t.join(); }
+};
+Reaper g_reaper;
+
 } // namespace
 
 extern "C" int bwahip_stream_run(bwahip_ctx *const *ctxs, int n_ctx, const bwahip_opt_t *opt, const bwahip_pestat_t *pes0,
@@ -89,6 +100,7 @@ extern "C" int bwahip_stream_run(bwahip_ctx *const *ctxs, int n_ctx, const bwahi
 	o.n_threads = opt->n_threads / n_ctx > 1 ? opt->n_threads / n_ctx : 1;   // opt->n_threads is the host-thread budget of the whole run
 	Driver d;
 	d.fd = out_fd; d.max_reads = st->max_reads;
+	const double t_call = now_s();
 	int rc = bwahip_fastq_open_mt(fq1, fq2, st->reader_threads, &d.rd);
 	if (rc) return rc;
 	st->n_reads = st->n_batches = st->sam_bytes = 0; st->seconds = st->reader_wait_s = st->write_s = st->gpu_busy_s = 0;
@@ -168,7 +180,11 @@ extern "C" int bwahip_stream_run(bwahip_ctx *const *ctxs, int n_ctx, const bwahi
 	for (int w = 0; w < n_ctx; ++w) th.emplace_back(worker, w);
 	for (auto &t : th) t.join();
 	wr.join();
-	bwahip_fastq_close(d.rd);
+	const double t_joined = now_s();
+	g_reaper.close_later(d.rd);
+	if (getenv("BWAHIP_STREAM_LOG"))
+		fprintf(stderr, "[bwahip] stream: open %.1f ms, first batch in -> last SAM byte out %.1f ms, joining the threads %.1f ms, handing the reader to the closer %.1f ms\n",
+		        (t_start - t_call) * 1e3, (d.t_last_write - t_start) * 1e3, (t_joined - d.t_last_write) * 1e3, (now_s() - t_joined) * 1e3);
 	st->n_reads = d.n_processed; st->n_batches = d.next_seq; st->sam_bytes = d.sam_bytes;
 	st->seconds = d.t_last_write - t_start; st->write_s = d.write_s;
 	for (int w = 0; w < n_ctx; ++w) { st->reader_wait_s += wait_s[w]; st->gpu_busy_s += busy_s[w]; }

@@ -9,7 +9,7 @@ set -e
 MODE=${1:-counters}; TAG=${2:-prof}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 if [ "$MODE" = counters ]; then
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --overlap 1 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log || echo "trace failed"
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --overlap 1 --no-cpu-baseline --no-e2e > $OUT/bench_under_trace.json 2> $OUT/trace.log || echo "trace failed"
   echo "trace done"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAIT_ANY"; do
