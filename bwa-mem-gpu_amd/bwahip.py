@@ -143,6 +143,16 @@ def lib():
     return L
 
 
+def big_bytes(ptr, n):
+    """n bytes at ptr as a bytes object; ctypes.string_at takes a C int, and a batch's SAM text can exceed 2^31 bytes."""
+    addr = ptr.value if hasattr(ptr, "value") else ptr
+    if isinstance(addr, bytes):                                # a c_char_p: take the address of its buffer
+        addr = C.cast(ptr, C.c_void_p).value
+    if n <= 0:
+        return b""
+    return bytes((C.c_char * n).from_address(addr))
+
+
 def _check(rc, what):
     if rc != 0:
         raise BwahipError(f"{what} failed: {ERRORS.get(rc, rc)}")
@@ -305,7 +315,7 @@ class Context:
         _check(lib().bwahip_process_seqs(self._h, C.byref(opt), n_processed, n, arr, pes0), "bwahip_process_seqs")
         out, ln = C.c_void_p(), C.c_int64()
         _check(lib().bwahip_seqs_take_sam(arr, n, C.byref(out), C.byref(ln)), "bwahip_seqs_take_sam")
-        sam = C.string_at(out, ln.value)
+        sam = big_bytes(out, ln.value)
         libc = C.CDLL(None)
         libc.free.argtypes = [C.c_void_p]
         libc.free(out)
@@ -316,7 +326,7 @@ class Context:
         opt = opt or default_opt()
         sam, ln, off = C.c_char_p(), C.c_int64(), C.POINTER(C.c_int64)()
         _check(lib().bwahip_process_seqs_text(self._h, C.byref(opt), n_processed, n, arr, pes0, C.byref(sam), C.byref(ln), C.byref(off)), "bwahip_process_seqs_text")
-        text = C.string_at(sam, ln.value)
+        text = big_bytes(sam, ln.value)
         return (text, [off[i] for i in range(n + 1)]) if want_offsets else text
 
     def last_pe_stats(self):
@@ -350,7 +360,7 @@ class Context:
     def batch_sam(self):
         out, ln = C.c_void_p(), C.c_int64()
         _check(lib().bwahip_batch_sam(self._h, C.byref(out), C.byref(ln), None), "bwahip_batch_sam")
-        sam = C.string_at(out, ln.value)
+        sam = big_bytes(out, ln.value)
         libc = C.CDLL(None)
         libc.free.argtypes = [C.c_void_p]
         libc.free(out)

@@ -175,8 +175,8 @@ struct ExtLaunch {
 	DevReg *spec_regs; int2 *spec_items; int *spec_n; int spec_min_chains;
 	int rank_sort_min;                           // dedup: lists at least this long try the wavefront rank sort first (shorter: one-lane introsort hides behind other wavefronts)
 	int *redo_list, *redo_n;                     // reads k_extend hands to k_extend_big (reference window beyond the LDS window)
-	int *dedup_list, *dedup_n;                   // reads k_extend leaves with more than one region: k_dedup sorts / dedups / patches them (two lists of n_reads: [0] the bulk, [1] the heavy reads)
-	int subset;                                  // k_extend / k_dedup: 0 all reads, 1 the heavy ones (first two classes of the launch order), 2 the others
+	int *dedup_list, *dedup_n;                   // reads k_extend leaves with more than one region: k_dedup sorts / dedups / patches them (three lists of n_reads: [0] the bulk, [1] the heavy reads, [2] what k_dedup_fast passes on to k_dedup)
+	int subset;                                  // k_extend / k_dedup: 0 all reads, 1 the heavy ones (first two classes of the launch order), 2 the others; k_dedup 3: list 2
 	uint8_t *big_t;                              // BWAHIP_EXT_BIG_GRID slabs of BWAHIP_EXT_BIG_T + 64 bytes
 	int lds_window;                              // largest reference window k_extend keeps in LDS (<= its compiled MAXT)
 };

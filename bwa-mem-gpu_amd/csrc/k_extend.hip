@@ -580,7 +580,7 @@ template <int CPL>
 __global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k_extend_spec(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
-	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ __attribute__((aligned(16))) uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
 	unsigned *const s_he = s_he_g + 64;
@@ -637,6 +637,86 @@ __global__ void k_spec_items(int n, const int *chain_n, int min_chains, int2 *it
 // k_extend_big, the same code with the window in a global-memory slab of BIG_T bases (tandem repeats: a chain may drift
 // by up to opt.w per merged seed, bwamem.c:203-217, so the window has no small bound; a wide -w widens it too).
 constexpr int BIG_T = BWAHIP_EXT_BIG_T;
+// mem_sort_dedup_patch (bwamem.c:444-496) for the ordinary short list -- at most FAST_N regions, no two keys equal in either sort, no pair of
+// regions that mem_patch_reg would align -- in a lean kernel of its own (k_dedup_fast): the list lives in LDS, the sorts are counts of smaller keys by shuffle
+// (without ties every correct sort is the reference's), the dedup pass runs on one lane.  Anything else (a tie, a patch candidate) returns -1
+// with the global list untouched, and the read goes to k_dedup.  Returns the new length; the finished list is written back.
+constexpr int FAST_N = 8;
+__device__ __forceinline__ int fast_dedup(const DevOpt &opt, const DevIndex &ix, DevReg *gav, int n, DevReg *s_a, DevReg *s_b, int l)
+{
+	const int64_t l_pac = ix.l_pac;
+	__syncthreads();
+	// sort by re (ks_introsort(mem_ars2)): one region per lane
+	int64_t key = 0;
+	if (l < n) key = gav[l].re;
+	int rank = 0; bool tie = false;
+	for (int u = 0; u < n; ++u) {
+		const int64_t ku = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)key, u) | (uint64_t)(uint32_t)__shfl((int)((uint64_t)key >> 32), u) << 32);
+		rank += ku < key ? 1 : 0;
+		tie |= ku == key && u != l;
+	}
+	if (__ballot(l < n && tie)) return -1;
+	if (l < n) { DevReg v = gav[l]; v.n_comp = 1; s_a[rank] = v; }
+	__threadfence_block(); __syncthreads();
+	// the redundancy pass (bwamem.c:451-480) on lane 0; a pair mem_patch_reg would go on to align ends the fast path
+	int bail = 0;
+	if (l == 0) {
+		for (int i = 1; i < n && !bail; ++i) {
+			DevReg *p = &s_a[i];
+			if (p->rid != s_a[i - 1].rid || p->rb >= s_a[i - 1].re + opt.max_chain_gap) continue;
+			for (int j = i - 1; j >= 0 && p->rid == s_a[j].rid && p->rb < s_a[j].re + opt.max_chain_gap; --j) {
+				DevReg *q = &s_a[j];
+				if (q->qe == q->qb) continue;
+				const int64_t orr = q->re - p->rb, oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+				const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+				const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+				if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
+					if (p->score < q->score) { p->qe = p->qb; break; }
+					else q->qe = q->qb;
+				} else if (q->rb < p->rb) {                          // mem_patch_reg's tests before it aligns (bwamem.c:419-429)
+					bool ok = true;
+					if (q->rb < l_pac && p->rb >= l_pac) ok = false;
+					if (ok && (q->qb >= p->qb || q->qe >= p->qe || q->re >= p->re)) ok = false;
+					if (ok) {
+						int w = (int)((q->re - p->rb) - (q->qe - p->qb));
+						w = w > 0 ? w : -w;
+						double rr = (double)(q->re - p->rb) / (p->re - q->rb) - (double)(q->qe - p->qb) / (p->qe - q->qb);
+						rr = rr > 0. ? rr : -rr;
+						if (q->re < p->rb || q->qe < p->qb) { if (w > opt.w << 1 || rr >= 0.05f) ok = false; }
+						else if (w > opt.w << 2 || rr >= 0.05f * 2) ok = false;
+					}
+					if (ok) { bail = 1; break; }
+				}
+			}
+		}
+	}
+	__threadfence_block(); __syncthreads();
+	if (__shfl(bail, 0)) return -1;
+	// drop the excluded entries (order kept), then sort by (score desc, rb, qb) (ks_introsort(mem_ars)); equal keys = identical hits: the full path's
+	const bool keep = l < n && s_a[l].qe > s_a[l].qb;
+	const unsigned long long km = __ballot(keep);
+	const int m = __popcll(km);
+	DevReg mine;
+	if (keep) mine = s_a[l];
+	const int pos = __popcll(km & ((1ull << l) - 1));               // its place after the compaction
+	int sc = 0, qb = 0; int64_t rb = 0;
+	if (keep) { sc = mine.score; rb = mine.rb; qb = mine.qb; }
+	int rank2 = 0; bool tie2 = false;
+	for (unsigned long long t = km; t; t &= t - 1) {
+		const int u = __ffsll((long long)t) - 1;
+		const int su = __shfl(sc, u), qu = __shfl(qb, u);
+		const int64_t ru = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)rb, u) | (uint64_t)(uint32_t)__shfl((int)((uint64_t)rb >> 32), u) << 32);
+		const bool lt_ut = su > sc || (su == sc && (ru < rb || (ru == rb && qu < qb)));
+		rank2 += lt_ut ? 1 : 0;
+		tie2 |= su == sc && ru == rb && qu == qb && u != l;
+	}
+	(void)pos;
+	if (__ballot(keep && tie2)) return -1;
+	if (keep) { if (mine.rid >= 0 && ix.anns[mine.rid].is_alt) mine.is_alt = 1; gav[rank2] = mine; }   // (bwamem.c:1091-1095 on the way out)
+	__threadfence_block(); __syncthreads();
+	return m;
+}
+
 // PHASE 0: both parts (k_extend_big); 1: the mem_chain2aln calls only -- a read left with more than one region is listed for k_dedup (its
 // sorts and the dedup pass want other registers and run as their own launch); 2: mem_sort_dedup_patch of a listed read.
 template <int CPL, bool BIGT, int PHASE>
@@ -1001,7 +1081,7 @@ template <int CPL>
 __global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k_extend(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
-	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ __attribute__((aligned(16))) uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ int s_stk_g[3 * 80 + 32];
 	int *const s_stk = s_stk_g + 16;
@@ -1010,13 +1090,32 @@ __global__ __launch_bounds__(64, (CPL <= 3 ? KEXT_W3 : CPL == 4 ? 4 : 1)) void k
 	// a.subset 1: the reads with many seeds left (the first two classes of the launch order), on their own stream with their own k_dedup behind
 	// them, so that their long extensions AND their long lists run beside the bulk; 2: all other reads; 0: everything (no launch order)
 	const int n_heavy = a.perm ? a.perm_counts[0] + a.perm_counts[1] : 0;
-	if (a.subset == 1) {
-		for (int idx = (int)blockIdx.x; idx < n_heavy; idx += (int)gridDim.x) { extend_read<CPL, false, 1>(a, a.perm[idx], s_q, s_t, s_mat, s_stk, s_he); __syncthreads(); }
-		return;
+	for (int idx = (int)blockIdx.x;; idx += (int)gridDim.x) {     // (one call site: subset 1 strides over the heavy reads, the others take one read)
+		if (a.subset == 1 ? idx >= n_heavy : (a.subset == 2 && idx < n_heavy)) break;
+		extend_read<CPL, false, 1>(a, a.perm ? a.perm[idx] : idx, s_q, s_t, s_mat, s_stk, s_he);
+		if (a.subset != 1) break;
+		__syncthreads();
 	}
-	if (a.subset == 2 && (int)blockIdx.x < n_heavy) return;
-	const int r = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
-	extend_read<CPL, false, 1>(a, r, s_q, s_t, s_mat, s_stk, s_he);
+}
+
+// The bulk's lists first go through fast_dedup, one read per wavefront: a quarter of all reads has two or three regions, and the full
+// k_dedup spends some fifteen dependent round trips on each.  What fast_dedup does not take goes on to list 2 for k_dedup.
+__global__ __launch_bounds__(64) void k_dedup_fast(ExtLaunch a)
+{
+	__shared__ __attribute__((aligned(16))) DevReg s_g[2 * FAST_N + 8];   // (4 unused records at either end: the lists are reached through generic pointers)
+	const int l = lane();
+	const int n_list = a.dedup_n[0];
+	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
+		const int r = a.dedup_list[it];
+		const int n = a.reg_n[r];
+		int m = -1;
+		if (n <= FAST_N) m = fast_dedup(a.opt, a.ix, a.regs + a.reg_base[r], n, s_g + 4, s_g + 4 + FAST_N, l);
+		if (l == 0) {
+			if (m >= 0) a.reg_n[r] = m;
+			else a.dedup_list[(size_t)2 * a.n_reads + atomicAdd(&a.dedup_n[2], 1)] = r;
+		}
+		__syncthreads();
+	}
 }
 
 // mem_sort_dedup_patch of the reads k_extend listed (more than one region), one read per wavefront
@@ -1024,7 +1123,7 @@ template <int CPL>
 __global__ __launch_bounds__(64) void k_dedup(ExtLaunch a)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
-	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ __attribute__((aligned(16))) uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ int s_stk_g[3 * 80 + 32];
 	int *const s_stk = s_stk_g + 16;
@@ -1035,7 +1134,7 @@ __global__ __launch_bounds__(64) void k_dedup(ExtLaunch a)
 	// instruction, its base register stays inside the LDS aperture (the array may well sit at LDS offset 0)
 	__shared__ __attribute__((aligned(16))) unsigned s_v_g[2048 + 128];
 	unsigned *const s_v = s_v_g + 64;
-	const int li = a.subset == 1 ? 1 : 0;
+	const int li = a.subset == 1 ? 1 : a.subset == 3 ? 2 : 0;   // the heavy reads' list, the list k_dedup_fast passed on, or all of the bulk
 	const int n_list = a.dedup_n[li];
 	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
 		extend_read<CPL, false, 2>(a, a.dedup_list[(size_t)li * a.n_reads + n_list - 1 - it], s_q, s_t, s_mat, s_stk, s_he, s_v, 2048);   // from the end of the list: the reads k_extend finished last are the ones with the longest lists
@@ -1098,7 +1197,7 @@ __global__ __launch_bounds__(64) void k_kat_ksw(DevOpt opt, int n, const int *pa
                                                 const uint8_t *t, const int64_t *toff, int *out6)
 {
 	__shared__ uint8_t s_q[MAXQ + 8];
-	__shared__ uint8_t s_t[MAXT + 8];
+	__shared__ __attribute__((aligned(16))) uint8_t s_t[MAXT + 8];
 	__shared__ int8_t s_mat[32];
 	__shared__ __attribute__((aligned(16))) unsigned s_he_g[WIN_MAX + 128];   // reached through generic pointers too (the sorts' tables): 256 bytes in front and behind are never handed out
 	unsigned *const s_he = s_he_g + 64;
@@ -1187,6 +1286,8 @@ template <int CPL> static void launch_extend_cpl(ExtLaunch a, hipStream_t st, hi
 		a.subset = 2;
 	} else a.subset = 0;
 	hipLaunchKernelGGL(k_extend<CPL>, dim3(a.n_reads), dim3(64), 0, st, a);
+	hipLaunchKernelGGL(k_dedup_fast, dim3(dgrid), dim3(64), 0, st, a);   // the ordinary short lists; the rest goes on to list 2
+	a.subset = 3;
 	hipLaunchKernelGGL(k_dedup<CPL>, dim3(dgrid), dim3(64), 0, st, a);
 }
 

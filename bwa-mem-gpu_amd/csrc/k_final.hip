@@ -779,7 +779,7 @@ constexpr int CG_TCAP_SMALL = 768;
 // 44 vs 47 ms (250 bp at 5 %) per million reads; 8 (64 VGPRs, spilling) loses in both
 __host__ __device__ constexpr size_t cigar_zslab_words(int tcap) { return (size_t)(tcap + 72) * 16; }   // covers both band kernels: (tlen + w + 4) / 4 and (2 tlen + 2 w) / 16 blocks of 64 words
 template <bool FAST, int CPLMAX>
-__global__ __launch_bounds__(64, FAST ? 4 : CPLMAX <= 3 ? 6 : 5) void k_cigar(FinLaunch a, int n_list)
+__global__ __launch_bounds__(64, FAST ? 7 : CPLMAX <= 3 ? 6 : 5) void k_cigar(FinLaunch a, int n_list)
 {
 	constexpr bool SMALL = FAST || CPLMAX <= 3;
 	constexpr int TCAP = SMALL ? CG_TCAP_SMALL : CG_MAXT, MC = FAST ? 8 : SMALL ? 160 : CG_MAXC, MMD = SMALL ? 512 : CG_MAXMD;
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(64, FAST ? 4 : CPLMAX <= 3 ? 6 : 5) void k_cigar(Fi
 	const int l = lane();
 	if (l < 25) s_mat[l] = a.opt.mat[l];
 	unsigned *zg = FAST ? nullptr : a.zslab + (size_t)blockIdx.x * cigar_zslab_words(TCAP);
-	for (int it = (int)blockIdx.x; it < n_list; it += (int)gridDim.x) {
+	for (int it = (int)blockIdx.x; it < n_list; it += FAST ? n_list : (int)gridDim.x) {   // (FAST: one task per workgroup, the grid is the list)
 		const long long t = FAST ? a.fast_list[it] : a.dp_list[it];
 		const int2 tk = a.tasks[t];
 		const int r = tk.x;

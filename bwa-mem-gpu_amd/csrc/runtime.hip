@@ -638,7 +638,7 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		el.counters = counters; el.err = err;
 		if ((rc = c->d_redo.ensure((size_t)(n + 4) * 4)) || (rc = c->d_big_t.ensure((size_t)BWAHIP_EXT_BIG_GRID * (BWAHIP_EXT_BIG_T + 64)))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 16, c->stream));
-		if ((rc = c->d_dedup.ensure(((size_t)2 * n + 4) * 4))) return rc;
+		if ((rc = c->d_dedup.ensure(((size_t)3 * n + 4) * 4))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_dedup.p, 0, 16, c->stream));
 		el.dedup_n = c->d_dedup.as<int>(); el.dedup_list = c->d_dedup.as<int>() + 4;
 		el.redo_n = c->d_redo.as<int>(); el.redo_list = c->d_redo.as<int>() + 4; el.big_t = c->d_big_t.as<uint8_t>(); el.lds_window = c->knobs.ext_lds_window;

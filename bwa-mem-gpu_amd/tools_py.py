@@ -144,6 +144,7 @@ def process_seqs_bulk(bw, ctx, opt, names, reads, qual=b"I", n_processed=0, pes0
     with numpy.  names: (n, w) NUL-terminated rows; reads: (n, rl) ASCII.  Returns (seconds inside the call, SAM bytes)."""
     import ctypes as C
     import time
+    big_bytes = bw.big_bytes
     assert SEQ_DTYPE.itemsize == C.sizeof(bw.Seq) == 56
     n, rl = reads.shape
     seqbuf = np.ascontiguousarray(reads).copy()             # converted to 0..4 codes in place, as the reference does
@@ -165,7 +166,7 @@ def process_seqs_bulk(bw, ctx, opt, names, reads, qual=b"I", n_processed=0, pes0
     rc = L.bwahip_seqs_take_sam(C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), n, C.byref(out), C.byref(ln))
     if rc != 0:
         raise bw.BwahipError(f"bwahip_seqs_take_sam failed: {bw.ERRORS.get(rc, rc)}")
-    sam = C.string_at(out, ln.value)
+    sam = big_bytes(out, ln.value)
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
     libc.free(out)
@@ -178,6 +179,7 @@ def bulk_caller(bw, ctx, opt, names, reads, qual=b"I", one_piece=False):
     import ctypes as C
     import time
     import zlib
+    big_bytes = bw.big_bytes
     n, rl = reads.shape
     pristine = np.ascontiguousarray(reads)
     seqbuf = pristine.copy()
@@ -203,7 +205,7 @@ def bulk_caller(bw, ctx, opt, names, reads, qual=b"I", one_piece=False):
             dt = time.time() - t0
             if rc != 0:
                 raise bw.BwahipError(f"bwahip_process_seqs_text failed: {bw.ERRORS.get(rc, rc)}")
-            crc = zlib.crc32(C.string_at(sam, ln.value)) if check else None
+            crc = zlib.crc32(big_bytes(sam, ln.value)) if check else None
             return dt, ln.value, crc
         rc = L.bwahip_process_seqs(ctx._h, C.byref(opt), 0, n, C.cast(arr.ctypes.data, C.POINTER(bw.Seq)), None)
         if rc != 0:
