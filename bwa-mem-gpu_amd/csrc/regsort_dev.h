@@ -48,6 +48,95 @@ __device__ __forceinline__ bool wave_rank_sort(const RegSort c, int n, int *idx,
 	return true;
 }
 
+// ---- helpers of the wavefront sort ----
+__device__ __forceinline__ bool rk_lt(int mode, const RegKey &a, const RegKey &b)      // a sorts before b
+{
+	if (mode == 0) return a.k64 < b.k64;
+	return a.score > b.score || (a.score == b.score && (a.k64 < b.k64 || (a.k64 == b.k64 && a.qb < b.qb)));
+}
+__device__ __forceinline__ bool rk_eq(int mode, const RegKey &a, const RegKey &b)
+{
+	return mode == 0 ? a.k64 == b.k64 : (a.score == b.score && a.k64 == b.k64 && a.qb == b.qb);
+}
+__device__ __forceinline__ RegKey rk_shfl(const RegKey &k, int src)
+{
+	RegKey o;
+	o.k64 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)k.k64, src) | (uint64_t)(uint32_t)__shfl((int)((uint64_t)k.k64 >> 32), src) << 32);
+	o.score = __shfl(k.score, src); o.qb = __shfl(k.qb, src);
+	return o;
+}
+
+// Count of smaller keys (<< 16 | index -> v[]) and "shares its key" (-> tied[]) of every element of a long list, by buckets: 64 sampled
+// keys, sorted, cut the key space into 65 ranges; an element's count is the size of the ranges below its own plus its rank inside its
+// range, and equal keys always share a range.  n x 64 comparisons to find the ranges and about n x n / 64 / 64 inside them, instead of
+// n x n / 64 (a list of 3 000 regions -- one end of a pair inside a repeat family, re-sorted after every rescued hit -- took 3.5 ms per
+// sort in the all-against-all count).  perm: n ints of scratch; lds: 256 words.  Returns a non-zero mask when any two keys are equal.
+__device__ unsigned long long rank_pass_bucketed(const RegSort c, int n, unsigned *v, uint8_t *tied, int *perm, unsigned *lds, int l)
+{
+	const int mode = c.mode;
+	RegKey *tile = reinterpret_cast<RegKey*>(lds);
+	// the splitters: lane s samples one key; sorted across the lanes by (key, lane), lane j then holds the j-th smallest
+	RegKey spl;
+	{
+		const RegKey ks = c.key[(long long)l * n / 64];
+		int rs = 0;
+		for (int u = 0; u < 64; ++u) { const RegKey ku = rk_shfl(ks, u); rs += (rk_lt(mode, ku, ks) || (rk_eq(mode, ku, ks) && u < l)) ? 1 : 0; }
+		is_sync();
+		tile[rs] = ks;
+		is_sync();
+		spl = tile[l];
+		is_sync();
+	}
+	int *hist = reinterpret_cast<int*>(lds), *base = hist + 66, *fill = base + 66;      // 65 ranges: 0 .. 64
+	for (int i = l; i < 3 * 66; i += 64) hist[i] = 0;
+	is_sync();
+	for (int tb = 0; tb < n; tb += 64) {                         // the range of every element = the number of splitters below its key
+		const int t = tb + l;
+		RegKey kt; kt.k64 = 0; kt.score = 0; kt.qb = 0;
+		if (t < n) kt = c.key[t];
+		int b = 0;
+		for (int sp = 0; sp < 64; ++sp) { const RegKey ks = rk_shfl(spl, sp); b += rk_lt(mode, ks, kt) ? 1 : 0; }
+		if (t < n) { v[t] = (unsigned)b; atomicAdd(&hist[b], 1); }
+	}
+	is_sync();
+	{                                                            // sizes -> starts (65 values on 64 lanes: the last one by hand)
+		const int h = hist[l];
+		int inc = h;
+		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (l >= d) inc += o; }
+		base[l] = inc - h;
+		if (l == 63) base[64] = inc;
+	}
+	is_sync();
+	for (int t = l; t < n; t += 64) { const int b = (int)v[t]; perm[base[b] + atomicAdd(&fill[b], 1)] = t; }
+	is_sync();
+	unsigned long long any_tie = 0;
+	for (int b = 0; b <= 64; ++b) {                              // inside a range: its members one per lane, 64 at a time, the others by shuffle
+		const int m = hist[b], start = base[b];
+		for (int jb = 0; jb < m; jb += 64) {
+			const int j = jb + l;
+			int t = -1;
+			RegKey kt; kt.k64 = 0; kt.score = 0; kt.qb = 0;
+			if (j < m) { t = perm[start + j]; kt = c.key[t]; }
+			int cnt = 0; bool tie = false;
+			for (int ub = 0; ub < m; ub += 64) {
+				RegKey ko; ko.k64 = 0; ko.score = 0; ko.qb = 0;
+				if (ub == jb) ko = kt;
+				else if (ub + l < m) ko = c.key[perm[start + ub + l]];
+				const int hi = m - ub < 64 ? m - ub : 64;
+				for (int u = 0; u < hi; ++u) {
+					const RegKey ku = rk_shfl(ko, u);
+					cnt += rk_lt(mode, ku, kt) ? 1 : 0;
+					tie |= rk_eq(mode, ku, kt) && ub + u != j;
+				}
+			}
+			if (j < m) { v[t] = (unsigned)(start + cnt) << 16 | (unsigned)t; tied[t] = tie ? 1 : 0; }
+			any_tie |= __ballot(j < m && tie);
+		}
+	}
+	is_sync();
+	return any_tie;
+}
+
 // ks_introsort(mem_ars2 / mem_ars) on idx[0..n) (identity on entry) by the whole wavefront, exact for any input: keys without ties are
 // placed by rank; with ties the quicksort phase of the reference's introsort is followed in parallel (isort_dev.h).
 //   work: 8-byte aligned global scratch of ws_work_ints(n) ints; stk: 240 ints (LDS); lds: 256 words of LDS.
@@ -87,6 +176,8 @@ __device__ bool wave_sort_exact(const RegSort c, int n, int *idx, int *work, int
 	uint8_t *tied = reinterpret_cast<uint8_t*>(work + is_scratch_ints(n) + n);
 	RegKey *tile = reinterpret_cast<RegKey*>(lds);               // 64 keys of 16 bytes
 	unsigned long long any_tie = 0;
+	if (n >= 384) any_tie = rank_pass_bucketed(c, n, v, tied, qs_scratch + 6 * (n / 64 + 1), lds, l);   // (perm: where the partition tables will be)
+	else
 	// count of smaller keys (and "has an equal one") of every element: four elements per lane and pass, the keys they are compared with
 	// coming by in tiles of 64 through LDS -- n^2 / 64 comparisons per lane, n / 256 tile loads per 256 elements
 	for (int base = 0; base < n; base += 256) {
