@@ -8,7 +8,8 @@ traffic_only = "--traffic-only" in sys.argv       # on the GPU box: only (re)wri
 src = os.path.join("gpurun_out", tag)
 os.makedirs(dst, exist_ok=True)
 if not traffic_only:
-    shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
+    if os.path.exists(os.path.join(src, "bench_default.json")):      # the unprofiled run may come from a later call (profile_round.sh bench)
+        shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
     shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, "bench_under_rocprof_trace.json"))
     # rocprofv3 writes one set of files per process; bench.py also runs the gather microbenchmark as a child: take bench.py's
     ks = [f for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True) if "k_smem" in open(f).read()]
