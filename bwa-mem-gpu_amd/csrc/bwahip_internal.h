@@ -135,6 +135,7 @@ struct SeedLaunch {
 	unsigned long long *counters;
 };
 int launch_seeds(const SeedLaunch &a, int64_t total_seeds, hipStream_t st);
+int launch_sa_densify(const DevIndex &ix, uint64_t *dense, int to_intv, hipStream_t st);   // SA rows between the sampled ones, computed on the GPU
 
 struct BtNodeOpaque { int w[48]; };              // sizeof(BtNode) in k_chain.hip (2 + 11 + 12 ints, pad, 11 x int64)
 struct ChainWOpaque { int64_t pos; int a, b, c, d; int64_t e; int f, g, h, i; };
@@ -278,6 +279,7 @@ struct PairLaunch {
 	// four per wavefront (k_matesw_sw): slot = sw_base[anchor's read] + 4 * anchor + orientation
 	const int64_t *sw_base; int *sw_cnt; SwRes *sw_res; int *sw_tasks; int2 *sw_info; int *sw_n;
 	uint8_t *slab; size_t slab_stride;           // k_matesw: per-workgroup global scratch (reference window, column maxima, long-query working set)
+	unsigned int *queue;                         // k_matesw's work-queue heads (one per instantiation)
 	unsigned long long *counters;                // [0] SW calls, [1] rescued regions
 	// pairing
 	const FinReg *fregs; const int *freg_n; const int *n_pri;   // after k_mark on the pe lists (fregs is written: sub / secondary updates of bwamem_pair.c:347-350, 359-365)
@@ -292,6 +294,7 @@ int launch_pestat(const PairLaunch &a, hipStream_t st);
 int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
 int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
+int launch_resc_order(const PairLaunch &a, int n_resc, int *scratch, hipStream_t st);   // rescue list by list length, longest first (scratch: 3 n_resc + 8 ints)
 int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st);
 int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st);   // subset 2: n_listed pairs of resc_list
 size_t matesw_slab_bytes(int64_t window);

@@ -44,6 +44,7 @@ struct HostBuf {
 struct Knobs {
 	int intv_cap = 96;          // BWAHIP_INTV_CAP: initial per-read interval capacity (grown on overflow)
 	int smem_lanes = 1;         // BWAHIP_SMEM_LANES: lanes per read in k_smem (1, 2, 4, 8)
+	int sa_intv = 1;            // BWAHIP_SA_INTV: interval of the SA table in HBM (1: every row, 8 bytes each; the index files' own interval or more: the files' table as it is); a table that would take over a quarter of the free HBM is built at the next interval that fits
 	int heavy_mult = -1;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never; -1: 10 for reads up to 200 bases, 30 above -- a 250 bp read at 5 % error needs 2 500 extends on average, and the hand-off is for the outliers)
 	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which a wavefront-per-read chaining kernel takes the read (< 0: off)
 	int rank_sort_min = 2;      // BWAHIP_RANK_SORT_MIN: dedup lists at least this long are sorted by the whole wavefront (shorter: the one-lane restatement of ks_introsort)
@@ -57,7 +58,7 @@ struct Knobs {
 	void from_env()
 	{
 		auto geti = [](const char *k, int &v) { if (const char *e = getenv(k)) v = atoi(e); };
-		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult);
+		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult); geti("BWAHIP_SA_INTV", sa_intv);
 		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final); geti("BWAHIP_GPU_PAIR", gpu_pair);
 		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
 		e2e_log = getenv("BWAHIP_E2E_LOG") != nullptr;
@@ -92,6 +93,7 @@ struct bwahip_ctx {
 	HostIndex host = {};                 // host copy: contig table + packed reference (always owned); FM-index arrays only when loaded from files
 	DevIndex ix;
 	DevBuf d_bwt, d_sa, d_pac, d_anns;
+	DevBuf d_sa_dense;                   // the SA table the kernels read when it is denser than the files' (launch_sa_densify); owned by the context that built it
 	// batch state
 	int n_reads = 0, max_len = 0;
 	int64_t total_bases = 0;
@@ -112,6 +114,7 @@ struct bwahip_ctx {
 	DevBuf d_task_lists;                 // k_cigar's two work lists (no-DP tasks, DP tasks)
 	DevBuf d_resc_flag;                  // one byte per pair: mate rescue works on it (finalised by the second k_mark / k_pair launch)
 	DevBuf d_zslab;                      // k_cigar's backtrack slabs
+	DevBuf d_resc_ord;                   // scratch of the rescue list's ordering
 	DevBuf d_pool, d_fmisc, d_fredo, d_bigz, d_rec_list, d_xa_list, d_sam_len, d_sam_off, d_sam;
 	HostBuf h_stage, h_sam, h_sam2;       // pinned staging: batch text in, SAM text out (two buffers taken in turn by bwahip_process_seqs_text)
 	int sam_flip = 0;

@@ -46,7 +46,7 @@ int final_setup(bwahip_ctx *c)
 	int rc;
 	if ((rc = dev_upload(c->d_ctg_names, names.data(), names.size(), c->stream)) || (rc = dev_upload(c->d_ctg_name_off, noff.data(), noff.size() * 4, c->stream)) ||
 	    (rc = dev_upload(c->d_ctg_anno, anno.data(), anno.size(), c->stream)) || (rc = dev_upload(c->d_ctg_anno_off, aoff.data(), aoff.size() * 4, c->stream)) ||
-	    (rc = c->d_fmisc.ensure(128))) return rc;
+	    (rc = c->d_fmisc.ensure(256))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return 0;
 }
@@ -99,7 +99,7 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	pl.logtab = c->d_logtab.as<double>();
 	pl.regs = c->d_regs.as<DevReg>(); pl.reg_base = c->d_reg_base.as<int64_t>(); pl.reg_n = c->d_reg_n.as<int>();
 	unsigned long long *fm = c->d_fmisc.as<unsigned long long>();
-	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5; pl.sw_n = (int*)(fm + 14);
+	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5; pl.sw_n = (int*)(fm + 14); pl.queue = (unsigned int*)(fm + 16);
 	bwahip_pestat_t pes[4];
 	if (pes0) memcpy(pes, pes0, sizeof pes);
 	else {
@@ -167,10 +167,12 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
 		if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->stream2))) return rc;   // the alignments against the unrescued lists, all at once
 		if (n_resc > 0) {
+			if ((rc = c->d_resc_ord.ensure(((size_t)3 * n_resc + 8) * 4)) || (rc = launch_resc_order(pl, n_resc, c->d_resc_ord.as<int>(), c->stream2))) return rc;
 			const int grid = std::min(n_resc, 2048);
 			pl.slab_stride = (matesw_slab_bytes(widest + c->max_len) + 255) & ~(size_t)255;
 			if ((rc = c->d_ms_slab.ensure(pl.slab_stride * (size_t)grid))) return rc;
 			pl.slab = c->d_ms_slab.as<uint8_t>();
+			HIP_TRY(hipMemsetAsync(pl.queue, 0, 8, c->stream2));
 			if ((rc = launch_matesw(pl, grid, c->stream2))) return rc;
 		}
 		HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
@@ -187,7 +189,7 @@ int run_final(bwahip_ctx *c, const bwahip_opt_t *opt, int64_t n_processed, const
 	if (n == 0) return 0;
 	if (pe && (n & 1)) return BWAHIP_EINVAL;
 	int rc;
-	HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 128, c->stream));
+	HIP_TRY(hipMemsetAsync(c->d_fmisc.p, 0, 256, c->stream));
 	if (timed) HIP_TRY(hipEventRecord(c->ev[20], c->stream));
 	PairLaunch pl;
 	const DevOpt dopt_pe = make_dev_opt(opt);

@@ -429,7 +429,13 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 	uint8_t *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
 	unsigned long long n_sw = 0, n_new = 0, max_sw = 0, n_inline = 0;
 	const int n_resc = *a.resc_n;
-	for (int it = (int)blockIdx.x; it < n_resc; it += (int)gridDim.x) {
+	// the pairs come from a queue, the ones with the longest lists first (k_resc_order): a pair inside a repeat family costs a thousand times an
+	// ordinary one, and a fixed share per workgroup left most of the kernel's duration to the unluckiest workgroup
+	for (;;) {
+		int it = 0;
+		if (l == 0) it = (int)atomicAdd(a.queue + (P == 16 ? 0 : 1), 1u);
+		it = __shfl(it, 0);
+		if (it >= n_resc) break;
 		const int p = a.resc_list[it];
 		const unsigned long long sw_before = n_sw, tp0 = wall_clock64();
 		int n_list[2] = { a.pe_n[p << 1], a.pe_n[p << 1 | 1] };
@@ -734,6 +740,32 @@ size_t matesw_slab_bytes(int64_t window)                            // window: t
 {
 	const size_t win = (size_t)window + 256;
 	return ((win + 63) / 64 * 64) + win * 2 + 256;                      // + one 16-bit column maximum per window base
+}
+
+// the rescue list ordered by the length of the pair's lists (the cost of mem_matesw's list work grows with it), longest first
+__global__ void k_resc_cost(PairLaunch a, int n_resc, int *cost)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_resc) return;
+	const int p = a.resc_list[i];
+	cost[i] = a.pe_n[p << 1] + a.pe_n[p << 1 | 1];
+}
+__global__ void k_resc_apply(int n_resc, const int *list, const int *perm, int *out)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_resc) out[i] = list[perm[i]];
+}
+// scratch: 3 * n_resc + 8 ints; on return a.resc_list[0..n_resc) is in the new order
+int launch_resc_order(const PairLaunch &a, int n_resc, int *scratch, hipStream_t st)
+{
+	if (n_resc <= 1) return 0;
+	int *cost = scratch + 8, *perm = cost + n_resc, *tmp = perm + n_resc;
+	hipLaunchKernelGGL(k_resc_cost, dim3((n_resc + 255) / 256), dim3(256), 0, st, a, n_resc, cost);
+	const int rc = launch_order(n_resc, cost, 1024, 256, 64, perm, scratch, st);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_resc_apply, dim3((n_resc + 255) / 256), dim3(256), 0, st, n_resc, a.resc_list, perm, tmp);
+	if (hipMemcpyAsync(a.resc_list, tmp, (size_t)n_resc * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return BWAHIP_ENODEV;
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
 int launch_pestat(const PairLaunch &a, hipStream_t st)

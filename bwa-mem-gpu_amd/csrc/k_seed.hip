@@ -135,6 +135,31 @@ __global__ __launch_bounds__(256) void k_seed_rid(SeedLaunch a, long long total)
 	a.seeds[sid].rid = dev_intv2rid(a.ix, rbeg, rbeg + a.seeds[sid].len);
 }
 
+// ------------------------------------------------------------- the suffix array, denser than the index files hold it
+// bwa index keeps SA[k] for every 32nd BWT row k and bwt_sa (bwt.c:86) walks LF steps from a row to the next sampled one: 31 dependent 64-byte
+// gathers per look-up on average (a step lands on a sampled row with probability 1/32), 290 per read -- 8 ms per 1 M-read batch, a quarter of
+// the BWT search itself.  With 288 GB of HBM the table can hold every row: k_sa_fill computes the rows in between ON THE GPU when the index is
+// loaded (SA[k] = SA[LF(k)] + 1, the very sum bwt_sa forms, so every look-up returns the value the reference computes), halving the interval
+// pass by pass; a pass resolves N / I_from rows in I_from steps each, i.e. one LF step per BWT row and pass.  The files stay bwa's.
+__global__ __launch_bounds__(256) void k_sa_spread(const uint64_t *sa, uint64_t n_sa, int shift, uint64_t *dense)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_sa; i += (uint64_t)gridDim.x * blockDim.x) dense[i << shift] = sa[i];
+}
+// rows k = (2j + 1) * to_intv, j < n_new: walk to a row that is a multiple of 2 * to_intv (filled by the earlier passes)
+__global__ __launch_bounds__(256) void k_sa_fill(DevIndex ix, uint64_t *dense, int dense_shift, uint64_t to_intv, uint64_t n_new)
+{
+	const uint64_t n_lanes = (uint64_t)gridDim.x * blockDim.x, mask = 2 * to_intv - 1;
+	uint64_t next = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t k0 = 0, k = 0, steps = 0;
+	bool have = false;
+	for (;;) {
+		if (!have && next < n_new) { k0 = k = (2 * next + 1) * to_intv; steps = 0; have = true; next += n_lanes; }
+		if (__ballot(have) == 0) break;
+		if (have && (k & mask) == 0) { dense[k0 >> dense_shift] = steps + dense[k >> dense_shift]; have = false; }
+		else if (have) { k = lane_lf(ix, k); ++steps; }
+	}
+}
+
 // ------------------------------------------------------------- known-answer kernels
 __global__ void k_kat_occ4(DevIndex ix, int n, const uint64_t *k, uint64_t *out)
 {
@@ -176,6 +201,20 @@ int launch_seeds(const SeedLaunch &a, int64_t total, hipStream_t st)
 	if (walks >= 2) hipLaunchKernelGGL(k_seed_walk<2>, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
 	else hipLaunchKernelGGL(k_seed_walk<1>, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
 	hipLaunchKernelGGL(k_seed_rid, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, (long long)total);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+// dense must hold (seq_len >> log2(to_intv)) + 1 entries; ix.sa / ix.sa_intv are the table of the index files
+int launch_sa_densify(const DevIndex &ix, uint64_t *dense, int to_intv, hipStream_t st)
+{
+	int dense_shift = 0, spread = 0;
+	while ((1 << dense_shift) < to_intv) ++dense_shift;
+	while ((to_intv << spread) < ix.sa_intv) ++spread;
+	if ((1 << dense_shift) != to_intv || (to_intv << spread) != ix.sa_intv) return BWAHIP_EINVAL;
+	hipLaunchKernelGGL(k_sa_spread, dim3(256 * 8), dim3(256), 0, st, ix.sa, ix.n_sa, spread, dense);
+	for (uint64_t I = (uint64_t)ix.sa_intv >> 1; I >= (uint64_t)to_intv; I >>= 1) {
+		const uint64_t n_new = (ix.seq_len / I + 1) / 2;       // odd multiples of I up to seq_len
+		if (n_new) hipLaunchKernelGGL(k_sa_fill, dim3(256 * 8), dim3(256), 0, st, ix, dense, dense_shift, I, n_new);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 int launch_kat_occ4(const DevIndex &ix, int n, const uint64_t *k, uint64_t *out, hipStream_t st)

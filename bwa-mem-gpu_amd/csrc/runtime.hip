@@ -193,6 +193,20 @@ int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, c
 	for (ix.sa_shift = 0; (1 << ix.sa_shift) < bwt->sa_intv; ++ix.sa_shift);
 	if ((1 << ix.sa_shift) != bwt->sa_intv) return BWAHIP_EINVAL;
 	if (bwt->bwt_size < ((bwt->seq_len + 127) / 128) * 16) return BWAHIP_EINVAL;   // every 128-base block must be present
+	// the SA table of the kernels: every row (or every sa_intv-th), filled in on the GPU from the files' every 32nd (k_seed.hip)
+	int want = c->knobs.sa_intv < 1 ? 1 : c->knobs.sa_intv;
+	while (want & (want - 1)) want &= want - 1;
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	while (want < ix.sa_intv && ((size_t)(ix.seq_len / want) + 1) * 8 > free_b / 4) want <<= 1;
+	if (want < ix.sa_intv) {
+		const size_t n_dense = (size_t)(ix.seq_len / want) + 1;
+		if ((rc = c->d_sa_dense.ensure(n_dense * 8))) return rc;
+		if ((rc = launch_sa_densify(ix, c->d_sa_dense.as<uint64_t>(), want, c->stream))) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		ix.sa = c->d_sa_dense.as<uint64_t>(); ix.n_sa = n_dense; ix.sa_intv = want;
+		for (ix.sa_shift = 0; (1 << ix.sa_shift) < want; ++ix.sa_shift);
+	}
 	return final_setup(c);
 }
 
@@ -242,7 +256,8 @@ int bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out)
 {
 	if (!src || !out || !src->d_bwt.p || !src->d_sa.p || !src->d_pac.p) return BWAHIP_EINVAL;
 	bwahip_bwt_t b = src->host.bwt;
-	b.bwt = (uint32_t*)src->d_bwt.p; b.sa = (uint64_t*)src->d_sa.p;
+	b.bwt = (uint32_t*)src->d_bwt.p;
+	b.sa = const_cast<uint64_t*>(src->ix.sa); b.sa_intv = src->ix.sa_intv; b.n_sa = src->ix.n_sa;   // the table src's kernels read (the dense one when src built it)
 	int rc = bwahip_init_device(&b, &src->host.bns, (const uint8_t*)src->d_pac.p, src->device, out);
 	if (rc) return rc;
 	(*out)->knobs = src->knobs; (*out)->intv_cap = src->knobs.intv_cap; (*out)->rg_id = src->rg_id;
@@ -302,14 +317,14 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_sa_dense, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
 	                   &c->d_reg_n, &c->d_srt, &c->d_dbg_chains, &c->d_dbg_seeds, &c->d_dbg_chain_n, &c->d_dbg_regs, &c->d_dbg_reg_n, &c->d_flt, &c->d_heavy, &c->d_perm, &c->d_spec_regs, &c->d_spec_items, &c->d_scan, &c->d_chain_big, &c->d_logtab, &c->d_redo, &c->d_big_t, &c->d_dedup, &c->d_cperm,
 	                   &c->d_ctg_names, &c->d_ctg_name_off, &c->d_ctg_anno, &c->d_ctg_anno_off, &c->d_rg, &c->d_qual, &c->d_qual_off, &c->d_names, &c->d_name_off, &c->d_comments, &c->d_comment_off,
 	                   &c->d_fregs, &c->d_fregs2, &c->d_fscr, &c->d_need, &c->d_xa_owner, &c->d_freg_n, &c->d_npri, &c->d_task_n, &c->d_rec_n, &c->d_task_base, &c->d_tasks, &c->d_aln_of_reg, &c->d_alns,
-	                   &c->d_resc_flag, &c->d_zslab, &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
+	                   &c->d_resc_flag, &c->d_zslab, &c->d_resc_ord, &c->d_pool, &c->d_fmisc, &c->d_fredo, &c->d_bigz, &c->d_rec_list, &c->d_xa_list, &c->d_sam_len, &c->d_sam_off, &c->d_sam,
 	                   &c->d_hist, &c->d_pair_tab, &c->d_nb, &c->d_pe_cap, &c->d_pe_base, &c->d_pe_regs, &c->d_pe_n, &c->d_pe_tmp, &c->d_pe_keys, &c->d_pe_idx, &c->d_resc, &c->d_ms_slab, &c->d_pe_read, &c->d_sw_cnt, &c->d_sw_base, &c->d_sw_res, &c->d_sw_tasks, &c->d_sw_info, &c->d_task_lists };
 	if (c->external_index) { c->d_bwt.p = nullptr; c->d_sa.p = nullptr; c->d_pac.p = nullptr; c->d_bwt.cap = c->d_sa.cap = c->d_pac.cap = 0; }
 	for (DevBuf *b : bufs) b->release();

@@ -289,6 +289,28 @@ def test_fm_known_answers_vs_oracle_lib(ctx, small_index):
     assert np.array_equal(got_sa, want_sa)
 
 
+def test_sa_table_densities_agree(small_index, tmp_path, monkeypatch):
+    """The SA table filled in on the GPU (every row, every 4th) returns for EVERY BWT row what the walk over the index files' every-32nd
+    table returns (bwt_sa, bwt.c:86); a clone shares the table; the SAM text does not depend on the density."""
+    seq_len = 2 * 1000000
+    rows = np.arange(0, seq_len + 1, dtype=np.uint64)
+    fq, seqs = _reads(small_index, tmp_path, "sa_dens", 600, 150, 10000, 2000, 500, 77)
+    names, _, quals = bw.read_fastq(fq)
+    got, sams = {}, {}
+    for intv in (32, 4, 1):
+        monkeypatch.setenv("BWAHIP_SA_INTV", str(intv))
+        with bw.Context(small_index["prefix"], 0) as c:
+            got[intv] = c.kat_sa(rows)
+            sams[intv] = c.process_seqs(names, seqs, quals)
+            if intv == 1:
+                with c.clone() as c2:
+                    assert np.array_equal(c2.kat_sa(rows), got[intv])
+    assert np.array_equal(np.sort(got[32][1:]), np.arange(seq_len, dtype=np.uint64))     # a permutation of the text positions
+    assert got[32][0] == np.uint64(2**64 - 1) or got[32][0] == seq_len                   # row 0: the sentinel's suffix as bwt_sa returns it
+    assert np.array_equal(got[4], got[32]) and np.array_equal(got[1], got[32])
+    assert sams[4] == sams[32] and sams[1] == sams[32]
+
+
 def test_extend_known_answers_vs_oracle_lib(ctx, small_index):
     """bwt_extend on the device for random walks (both directions), incl. size-1 intervals."""
     import ctypes as C
