@@ -132,6 +132,7 @@ def lib():
     L.bwahip_kat_introsort.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bwahip_kat_occ4.argtypes = [vp, C.c_int, vp, vp]
     L.bwahip_kat_sa.argtypes = [vp, C.c_int, vp, vp]
+    L.bwahip_kat_kmer_table.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     L.bwahip_kat_extend.argtypes = [vp, C.c_int, vp, vp, vp]
     L.bwahip_kat_ksw_extend.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bwahip_align_batch.argtypes = [vp, C.POINTER(Opt), C.c_int, C.POINTER(Seq), C.POINTER(AlnRegV)]
@@ -390,7 +391,7 @@ class Context:
         names = ["extend", "blocks", "sa", "lf", "intv", "seeds", "cells", "max_extends", "chain_build_max", "chain_sort_max", "chain_flt_max",
                  "chain_write_max", "max_seeds", "max_chains", "ext_max", "ext_dedup_max", "heavy_blocks", "heavy_intv", "heavy_reads",
                  "dp_rows_1col", "dp_rows_ncol", "dedup_sort1_max", "dedup_loop_max", "dedup_sort2_max",
-                 "pass3_blocks", "pass3_intv", "_26", "_27", "_28", "_29", "_30", "_31"]
+                 "pass3_blocks", "pass3_intv", "pass3_jumped", "_27", "_28", "_29", "_30", "_31"]
         return {k: int(buf[i]) for i, k in enumerate(names)}
 
     def kat_introsort(self, k64, score, qb, mode):
@@ -413,6 +414,12 @@ class Context:
         out = np.zeros(len(k), dtype=np.uint64)
         _check(lib().bwahip_kat_sa(self._h, len(k), k.ctypes.data, out.ctypes.data), "bwahip_kat_sa")
         return out
+
+    def kat_kmer_table(self):
+        """(K, mismatches): the interval table against forward bwt_extend calls (bwahip_kat_kmer_table)."""
+        k, bad = C.c_int(), C.c_uint64()
+        _check(lib().bwahip_kat_kmer_table(self._h, C.byref(k), C.byref(bad)), "bwahip_kat_kmer_table")
+        return k.value, bad.value
 
     def kat_ksw_extend(self, params, q, qoff, t, toff):
         params = np.ascontiguousarray(params, dtype=np.int32)

@@ -25,7 +25,11 @@ struct DevIndex {
 	uint64_t primary, L2[5], seq_len, n_sa;
 	int64_t l_pac;
 	int sa_intv, sa_shift, n_seqs;
+	// the bi-intervals of all strings of 1..kmer_k bases (k_smem.hip, "interval table"); kmer_k = 0: none
+	const uint4 *kmer; int kmer_k;
 };
+// entry of the string s_0 s_1 .. s_{L-1} (s_t at bits 2t of `code`): kmer[kmer_off(L) + code]; levels follow each other, 4^L entries each
+__host__ __device__ inline uint64_t kmer_off(int L) { return (0x5555555555555555ull & ((1ull << 2 * L) - 1)) - 1; }
 
 // Options the kernels read (a flat copy of the fields of mem_opt_t that the hot path uses).
 struct DevOpt {
@@ -42,7 +46,7 @@ struct DevOpt {
 // Work counters kept in HBM, bumped once per wavefront at kernel exit (bwahip_batch_counters).
 enum { CNT_EXTEND = 0, CNT_BLOCKS, CNT_SA, CNT_LF, CNT_INTV, CNT_SEEDS, CNT_CELLS, CNT_MAX_EXT /* most bwt_extend calls of one read */,
        CNT_HEAVY_BLOCKS = 16, CNT_HEAVY_INTV, CNT_HEAVY_READS, CNT_ROWS1 /* DP rows, 1 column per lane */, CNT_ROWSN /* DP rows, CPL columns per lane */,
-       CNT_P3_BLOCKS = 24, CNT_P3_INTV, CNT_N = 32 };
+       CNT_P3_BLOCKS = 24, CNT_P3_INTV, CNT_P3_JUMPED /* pass-3 extensions the interval table stood in for */, CNT_N = 32 };
 // The counters are kept in CNT_SLOTS copies (rows of CNT_N); a wavefront updates the row picked by its position in the
 // launch and the host folds the rows (sum, or max for the *_max entries).  One shared row made every wavefront's
 // end-of-work atomics queue up on the same L2 line: with a million wavefronts that alone cost tens of milliseconds.
@@ -123,6 +127,8 @@ int launch_smem(const SmemLaunch &a, int group_lanes, hipStream_t st);
 int launch_pack4(const SmemLaunch &a, hipStream_t st);
 int launch_smem_heavy(const SmemLaunch &a, hipStream_t st);
 int launch_smem3(const SmemLaunch &a, hipStream_t st);
+int launch_kmer_table(const DevIndex &ix, uint4 *tab, int K, hipStream_t st);   // fills kmer_off(K + 1) entries
+int launch_kmer_check(const DevIndex &ix, int L, unsigned long long *bad, hipStream_t st);
 int launch_intv_sort(const SmemLaunch &a, hipStream_t st);
 int smem_default_groups(int group_lanes);
 

@@ -172,7 +172,7 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 			pl.slab_stride = (matesw_slab_bytes(widest + c->max_len) + 255) & ~(size_t)255;
 			if ((rc = c->d_ms_slab.ensure(pl.slab_stride * (size_t)grid))) return rc;
 			pl.slab = c->d_ms_slab.as<uint8_t>();
-			HIP_TRY(hipMemsetAsync(pl.queue, 0, 8, c->stream2));
+			HIP_TRY(hipMemsetAsync(pl.queue, 0, 16, c->stream2));
 			if ((rc = launch_matesw(pl, grid, c->stream2))) return rc;
 		}
 		HIP_TRY(hipEventRecord(c->ev_join, c->stream2));

@@ -407,9 +407,12 @@ __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 	if (gl == 0) { SwRes o_ = { 2, aln.score, aln.te, aln.qe, aln.score2, aln.te2, aln.tb, aln.qb }; a.sw_res[slot] = o_; }
 }
 
-template <int P>
-__global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
+// BIG: the pairs with a list beyond MS_LIST regions (their lists stay in global memory): this instantiation has no list arrays in LDS, so
+// eight of its workgroups fit a CU instead of two -- their work is chains of dependent accesses, and a human-like repeat load is all BIG pairs
+template <int P, bool BIG>
+__global__ __launch_bounds__(64, BIG ? 2 : 1) void k_matesw(PairLaunch a)
 {
+	constexpr int LDS_LIST = BIG ? 1 : MS_LIST;
 	constexpr int CELLS = P == 16 ? 256 : (MS_MAXQ + 7) / 8 * 8;
 	__shared__ uint8_t s_q[MS_MAXQ + 8];
 	__shared__ int8_t s_mat[32];
@@ -419,10 +422,10 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 	__shared__ uint8_t s_tw[4096];
 	__shared__ uint16_t s_cm[4096];
 	// 16-byte aligned: the lists are reached through generic pointers (LDS or global slots), i.e. flat 16-byte accesses
-	__shared__ GuardedLds<MS_LIST> s_list_g, s_tmp_g;          // (a spare record in front and behind: see ListRef)
-	__shared__ __attribute__((aligned(16))) RegKey s_keys[MS_LIST];
+	__shared__ GuardedLds<LDS_LIST> s_list_g, s_tmp_g;         // (a spare record in front and behind: see ListRef)
+	__shared__ __attribute__((aligned(16))) RegKey s_keys[LDS_LIST];
 	const ListRef s_list = ListRef::lds(s_list_g), s_tmp = ListRef::lds(s_tmp_g);
-	__shared__ int s_idx[2 * MS_LIST];
+	__shared__ int s_idx[2 * LDS_LIST];
 	const int l = lane();
 	if (l < 25) s_mat[l] = a.opt.mat[l];
 	__syncthreads();
@@ -433,10 +436,11 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 	// ordinary one, and a fixed share per workgroup left most of the kernel's duration to the unluckiest workgroup
 	for (;;) {
 		int it = 0;
-		if (l == 0) it = (int)atomicAdd(a.queue + (P == 16 ? 0 : 1), 1u);
+		if (l == 0) it = (int)atomicAdd(a.queue + (P == 16 ? 0 : 1) + (BIG ? 2 : 0), 1u);
 		it = __shfl(it, 0);
 		if (it >= n_resc) break;
 		const int p = a.resc_list[it];
+		if ((a.pe_cap[p << 1] > MS_LIST || a.pe_cap[p << 1 | 1] > MS_LIST) != BIG) continue;   // the other instantiation's pair
 		const unsigned long long sw_before = n_sw, tp0 = wall_clock64();
 		int n_list[2] = { a.pe_n[p << 1], a.pe_n[p << 1 | 1] };
 		// sort scratch of a list lives behind its slots' spare copy: tmp list, keys and index arrays sized by the capacity
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(64) void k_matesw(PairLaunch a)
 			// the mate's list is worked on in LDS when its capacity fits (the insert / sort / dedup steps are chains of dependent
 			// accesses: ~1 ms per rescue through global memory, measured), else in its global slots
 			DevReg *G = a.pe_regs + a.pe_base[rm];
-			const bool in_lds = a.pe_cap[rm] <= MS_LIST;
+			const bool in_lds = !BIG;
 			const DevReg *snap = a.regs + a.reg_base[r];            // b[i]: the end's own regions as mem_align1_core left them
 			// two call sites on purpose: each is compiled for its own address space (LDS / global).  Through one generic pointer the
 			// list code became flat instructions with folded offsets (base = &L[i-1], offset +80); the hardware picks the aperture
@@ -792,8 +796,10 @@ int launch_pe_copy(const PairLaunch &a, hipStream_t st)
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st)
 {
 	if (grid <= 0) return 0;
-	hipLaunchKernelGGL(k_matesw<16>, dim3(grid), dim3(64), 0, st, a);   // mates under 250 bases: byte kernel
-	hipLaunchKernelGGL(k_matesw<8>, dim3(grid), dim3(64), 0, st, a);    // longer mates: word kernel (after the byte one: a pair may need both)
+	hipLaunchKernelGGL((k_matesw<16, true>), dim3(grid), dim3(64), 0, st, a);    // mates under 250 bases: byte kernel; the pairs with long lists first
+	hipLaunchKernelGGL((k_matesw<16, false>), dim3(grid), dim3(64), 0, st, a);
+	hipLaunchKernelGGL((k_matesw<8, true>), dim3(grid), dim3(64), 0, st, a);     // longer mates: word kernel (after the byte one: a pair may need both)
+	hipLaunchKernelGGL((k_matesw<8, false>), dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st)

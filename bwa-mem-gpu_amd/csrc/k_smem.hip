@@ -130,6 +130,62 @@ __device__ __forceinline__ void finish_pass12(const SmemLaunch &a, int rd, int n
 
 __device__ __forceinline__ int base_or_minus1(int b) { return b > 3 ? -1 : b; }
 
+// ------------------------------------------------------------- the interval table
+// The bi-interval bwt_extend (bwt.c:262) arrives at depends only on the STRING matched so far -- (first row of the string's suffix-array
+// interval, first row of its reverse complement's, size) -- not on the order the bases were added in.  With 288 GB of HBM the answers for
+// all strings of up to K bases are kept (K = 14: 358 M entries of 16 bytes, 5.7 GB), filled on the GPU when the index is loaded, level by
+// level with the very same extension (4^L lanes, one block pair each); a string that does not occur has size 0 and so do all its extensions,
+// exactly as bwt_extend returns them (only the size of such a result is ever looked at).
+// Who reads it: k_smem3 (bwt_seed_strategy1 looks at no result before min_seed_len bases, so the first K - 1 extensions of every start
+// are ONE look-up: 3.4 -> 1.6 ms per 1 M reads at K = 14).  k_smem does NOT: answering its short-string extensions from the table (half of
+// all its calls: the first forward steps and the triangle of the backward sweep) was measured twice on the 3.1 Gbp index -- as a second
+// source at the convergent step 30.4 -> 28.5 ms against 26.2 ms without the extra code (the kernel is bound by the instructions of an
+// iteration, not by its Occ requests, and the iterations stay), and answered inside the run-up, one dependent gather after the other while
+// the other lanes of the wavefront wait, 46 ms.
+__global__ __launch_bounds__(256) void k_kmer_level(DevIndex ix, uint4 *tab, int L)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	if (L == 1) {
+		const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+		if (c < 4) { Bi ik; set_intv(ix, c, ik); tab[kmer_off(1) + c] = pack_entry(ik.x0, ik.x1, ik.x2, 0); }
+		return;
+	}
+	const uint64_t n_par = 1ull << 2 * (L - 1);
+	const uint4 *par = tab + kmer_off(L - 1);
+	uint4 *out = tab + kmer_off(L);
+	for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_par; w += stride) {
+		Bi ik; uint64_t e_;
+		unpack_entry(par[w], ik.x0, ik.x1, ik.x2, e_);
+		uint64_t tk[4], tl[4];
+		const bool live = ik.x2 != 0;
+		const uint64_t k = ik.x0 - 1, l = k + ik.x2;
+		lane_occ4_pair(ix, live ? k : 0, live ? l : 0, live, tk, tl);
+		const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+		const uint64_t b3 = ik.x1 + (ik.x0 <= ix.primary && ik.x0 + ik.x2 - 1 >= ix.primary), b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
+		const uint4 zero = make_uint4(0, 0, 0, 0);
+		out[w << 2 | 0] = live ? pack_entry(L2_at(ix, 0) + 1 + tk[0], b0, s0, 0) : zero;   // the string with base c put in FRONT: backward extension
+		out[w << 2 | 1] = live ? pack_entry(L2_at(ix, 1) + 1 + tk[1], b1, s1, 0) : zero;
+		out[w << 2 | 2] = live ? pack_entry(L2_at(ix, 2) + 1 + tk[2], b2, s2, 0) : zero;
+		out[w << 2 | 3] = live ? pack_entry(L2_at(ix, 3) + 1 + tk[3], b3, s3, 0) : zero;
+	}
+}
+// known-answer kernel: every entry of level L against the FORWARD extension of its prefix's entry (the table was filled by backward extensions:
+// the two agree iff the bi-interval is a function of the string alone)
+__global__ __launch_bounds__(256) void k_kmer_check(DevIndex ix, const uint4 *tab, int L, unsigned long long *bad)
+{
+	const uint64_t n = 1ull << 2 * L, stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n; w += stride) {
+		Bi pre, got, o; uint64_t e_;
+		unpack_entry(tab[kmer_off(L - 1) + (w & ((1ull << 2 * (L - 1)) - 1))], pre.x0, pre.x1, pre.x2, e_);
+		unpack_entry(tab[kmer_off(L) + w], got.x0, got.x1, got.x2, e_);
+		const int last = (int)(w >> 2 * (L - 1)) & 3;
+		const bool live = pre.x2 != 0;
+		lane_extend_c(ix, pre, 0, 3 - last, live, o);
+		const bool ok = live ? (o.x2 == got.x2 && (o.x2 == 0 || (o.x0 == got.x0 && o.x1 == got.x1))) : got.x2 == 0;
+		if (!ok) atomicAdd(bad, 1ull);
+	}
+}
+
 // G = lanes per read: 8 (one quad per Occ block of an extend) or 4 (one quad does both blocks; 16 reads per wavefront)
 template <int G>
 __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
@@ -506,7 +562,8 @@ __global__ __launch_bounds__(256) void k_smem3(SmemLaunch a)
 	const uint64_t *qrow = nullptr; uint64_t qw = 0; int qwi = -1;
 	DevIntv *U = a.raw;
 	Bi ik = { 0, 0, 0 };
-	unsigned n_ext = 0, n_blk = 0, n_new = 0;
+	unsigned n_ext = 0, n_blk = 0, n_new = 0, n_jump = 0;
+	const int kj = ix.kmer_k < min_seed_len ? ix.kmer_k : min_seed_len;
 	for (;;) {
 		if (st == P_IDLE && next < a.n_reads) {
 			rd = (int)next; next += n_lanes;
@@ -521,8 +578,20 @@ __global__ __launch_bounds__(256) void k_smem3(SmemLaunch a)
 		for (int spin = 0; spin < 4096 && !need && st != P_IDLE; ++spin) {
 			if (st == P_SCAN) {
 				while (x < len && qbase(qrow, x, qw, qwi) > 3) ++x;   // bwamem.c:170,181
-				if (x < len) { set_intv(ix, qbase(qrow, x, qw, qwi), ik); i = x + 1; st = P_EXT; }
-				else { a.raw_n[rd] = out_n; st = P_IDLE; }
+				if (x >= len) { a.raw_n[rd] = out_n; st = P_IDLE; }
+				else if (kj < 2) { set_intv(ix, qbase(qrow, x, qw, qwi), ik); i = x + 1; st = P_EXT; }
+				else {
+					// the first kj bases in one look-up of the interval table: no result before min_seed_len bases is ever looked at (bwt.c:366)
+					uint32_t code = (uint32_t)qbase(qrow, x, qw, qwi);
+					int m = 1, b = 4;
+					while (m < kj && x + m < len && (b = qbase(qrow, x + m, qw, qwi)) < 4) { code |= (uint32_t)b << 2 * m; ++m; }
+					n_jump += m - 1;
+					if (m == kj) {
+						uint64_t e_;
+						unpack_entry(ix.kmer[kmer_off(kj) + code], ik.x0, ik.x1, ik.x2, e_);
+						i = x + kj; st = P_EXT;
+					} else x = x + m < len ? x + m + 1 : len;        // an ambiguous base or the read's end comes first: bwt.c:376-378
+				}
 			} else {
 				const int bq = i < len ? qbase(qrow, i, qw, qwi) : 4;
 				if (bq < 4) { need = true; cb = 3 - bq; }
@@ -543,11 +612,12 @@ __global__ __launch_bounds__(256) void k_smem3(SmemLaunch a)
 			} else { ik = o; ++i; }
 		}
 	}
-	unsigned long long e = n_ext, b = n_blk, o = n_new;
-	for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); o += __shfl_xor(o, m); }
+	unsigned long long e = n_ext + n_jump, b = n_blk, o = n_new, jm = n_jump;
+	for (int m = 32; m; m >>= 1) { e += __shfl_xor(e, m); b += __shfl_xor(b, m); o += __shfl_xor(o, m); jm += __shfl_xor(jm, m); }
 	if (lane_id() == 0 && e) {
 		unsigned long long *cnt = cnt_row(a.counters);
 		atomicAdd(&cnt[CNT_EXTEND], e); atomicAdd(&cnt[CNT_BLOCKS], b); atomicAdd(&cnt[CNT_INTV], o);
+		if (jm) atomicAdd(&cnt[CNT_P3_JUMPED], jm);            // (the blocks of the jumped extends are not in CNT_BLOCKS: their intervals were never formed)
 		atomicAdd(&cnt[CNT_P3_BLOCKS], b); atomicAdd(&cnt[CNT_P3_INTV], o);
 	}
 }
@@ -574,6 +644,23 @@ int launch_pack4(const SmemLaunch &a, hipStream_t st)
 {
 	const int64_t words = (int64_t)a.n_reads * a.seq4_stride;
 	hipLaunchKernelGGL(k_pack4, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, a.n_reads, a.seq, a.off, a.seq4, a.seq4_stride);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+
+int launch_kmer_table(const DevIndex &ix, uint4 *tab, int K, hipStream_t st)
+{
+	for (int L = 1; L <= K; ++L) {
+		const uint64_t n_par = L == 1 ? 4 : 1ull << 2 * (L - 1);
+		const unsigned blocks = (unsigned)std::min<uint64_t>((n_par + 255) / 256, 256 * 16);
+		hipLaunchKernelGGL(k_kmer_level, dim3(blocks), dim3(256), 0, st, ix, tab, L);
+	}
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_kmer_check(const DevIndex &ix, int L, unsigned long long *bad, hipStream_t st)
+{
+	if (L < 2 || L > ix.kmer_k) return BWAHIP_EINVAL;
+	const unsigned blocks = (unsigned)std::min<uint64_t>(((1ull << 2 * L) + 255) / 256, 256 * 16);
+	hipLaunchKernelGGL(k_kmer_check, dim3(blocks), dim3(256), 0, st, ix, ix.kmer, L, bad);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 

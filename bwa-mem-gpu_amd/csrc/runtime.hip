@@ -207,6 +207,23 @@ int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, c
 		ix.sa = c->d_sa_dense.as<uint64_t>(); ix.n_sa = n_dense; ix.sa_intv = want;
 		for (ix.sa_shift = 0; (1 << ix.sa_shift) < want; ++ix.sa_shift);
 	}
+	// the interval table of the BWT search (k_smem.hip): shared by the clones of the context that built it
+	if (c->share_from) { ix.kmer = c->share_from->ix.kmer; ix.kmer_k = c->share_from->ix.kmer_k; }
+	else {
+		int K = c->knobs.kmer_k > 16 ? 16 : c->knobs.kmer_k;
+		int k_len = 1;
+		while (k_len < 16 && (1ull << 2 * k_len) < ix.seq_len) ++k_len;          // longer strings than log4 of the text mostly do not occur
+		if (K > k_len) K = k_len;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		while (K >= 2 && (kmer_off(K + 1) + 4) * 16 > free_b / 4) --K;
+		if (K >= 2) {
+			if ((rc = c->d_kmer.ensure((kmer_off(K + 1) + 4) * 16))) return rc;
+			if ((rc = launch_kmer_table(ix, c->d_kmer.as<uint4>(), K, c->stream))) return rc;
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			ix.kmer = c->d_kmer.as<uint4>(); ix.kmer_k = K;
+		}
+	}
+	if (c->knobs.verbose) fprintf(stderr, "[bwahip] index in HBM: SA every %d rows (%.2f GB), interval table of strings up to %d bases (%.2f GB)\n", ix.sa_intv, ix.n_sa * 8 / 1e9, ix.kmer_k, ix.kmer_k ? (kmer_off(ix.kmer_k + 1) + 4) * 16 / 1e9 : 0.);
 	return final_setup(c);
 }
 
@@ -229,7 +246,12 @@ int bwahip_init(const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, const uint8_t 
 	return 0;
 }
 
+static int init_device_impl(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out, const bwahip_ctx *share_from);
 int bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out)
+{
+	return init_device_impl(bwt_dev, bns, pac_dev, device, out, nullptr);
+}
+static int init_device_impl(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, const uint8_t *pac_dev, int device, bwahip_ctx **out, const bwahip_ctx *share_from)
 {
 	if (!bwt_dev || !bns || !pac_dev || !out || !bwt_dev->bwt || !bwt_dev->sa) return BWAHIP_EINVAL;
 	int n_dev = 0;
@@ -238,7 +260,7 @@ int bwahip_init_device(const bwahip_bwt_t *bwt_dev, const bwahip_bns_t *bns, con
 		return BWAHIP_ENODEV;
 	}
 	bwahip_ctx *c = new bwahip_ctx();
-	c->device = device; c->external_index = true;
+	c->device = device; c->external_index = true; c->share_from = share_from;
 	// host copy of the contig table, and of the packed reference read back from the adopted device array (l_pac/4+1 bytes),
 	// so that a rank that received its index over RCCL can run bwahip_process_seqs like the rank that loaded it
 	int rc = bwahip_copy_host_index(bwt_dev, bns, nullptr, &c->host);
@@ -258,7 +280,7 @@ int bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out)
 	bwahip_bwt_t b = src->host.bwt;
 	b.bwt = (uint32_t*)src->d_bwt.p;
 	b.sa = const_cast<uint64_t*>(src->ix.sa); b.sa_intv = src->ix.sa_intv; b.n_sa = src->ix.n_sa;   // the table src's kernels read (the dense one when src built it)
-	int rc = bwahip_init_device(&b, &src->host.bns, (const uint8_t*)src->d_pac.p, src->device, out);
+	int rc = init_device_impl(&b, &src->host.bns, (const uint8_t*)src->d_pac.p, src->device, out, src);
 	if (rc) return rc;
 	(*out)->knobs = src->knobs; (*out)->intv_cap = src->knobs.intv_cap; (*out)->rg_id = src->rg_id;
 	return 0;
@@ -317,7 +339,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_sa_dense, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_sa_dense, &c->d_kmer, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
@@ -451,6 +473,24 @@ int bwahip_kat_sa(bwahip_ctx *c, int n, const uint64_t *k, uint64_t *out)
 	if (!rc && hipMemcpyAsync(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
 	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
 	dk.release(); dout.release();
+	return rc;
+}
+
+int bwahip_kat_kmer_table(bwahip_ctx *c, int *k_out, uint64_t *bad_out)
+{
+	if (!c || !k_out || !bad_out) return BWAHIP_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	*k_out = c->ix.kmer_k; *bad_out = 0;
+	if (c->ix.kmer_k < 2) return 0;
+	DevBuf d; int rc;
+	if ((rc = d.ensure(16))) return rc;
+	HIP_TRY(hipMemsetAsync(d.p, 0, 16, c->stream));
+	for (int L = 2; L <= c->ix.kmer_k && !rc; ++L) rc = launch_kmer_check(c->ix, L, d.as<unsigned long long>(), c->stream);
+	unsigned long long bad = 0;
+	if (!rc && hipMemcpyAsync(&bad, d.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
+	d.release();
+	*bad_out = bad;
 	return rc;
 }
 

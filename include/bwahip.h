@@ -318,6 +318,9 @@ int bwahip_batch_counters(bwahip_ctx *ctx, uint64_t *counters, int n);
 /* Known-answer helpers used by the parity tests: device Occ/extend/SA on arrays of inputs. */
 int bwahip_kat_occ4(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *cnt4_out);
 int bwahip_kat_sa(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *sa_out);
+/* The interval table of the BWT search (strings of up to *k_out bases): every entry of every length against bwt_extend (bwt.c:262) run
+ * FORWARD from the entry of the string without its last base (the table itself is filled by backward extensions); *bad_out = mismatches. */
+int bwahip_kat_kmer_table(bwahip_ctx *ctx, int *k_out, uint64_t *bad_out);
 int bwahip_kat_extend(bwahip_ctx *ctx, int n, const uint64_t *ik3, const int *is_back, uint64_t *ok12_out);
 int bwahip_kat_ksw_extend(bwahip_ctx *ctx, int n, const int *params /*n x 10*/, const uint8_t *q, const int64_t *qoff,
                           const uint8_t *t, const int64_t *toff, int *out6 /*n x 6*/);

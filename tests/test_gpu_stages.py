@@ -311,6 +311,27 @@ def test_sa_table_densities_agree(small_index, tmp_path, monkeypatch):
     assert sams[4] == sams[32] and sams[1] == sams[32]
 
 
+def test_interval_table_entries_equal_forward_extension(ctx, small_index, tmp_path, monkeypatch):
+    """The interval table of the BWT search is filled by BACKWARD extensions; every entry of every length must equal the FORWARD extension
+    (bwt_extend, bwt.c:262, is_back = 0) of the entry of the string without its last base, i.e. the bi-interval is a function of the string
+    alone -- and the SAM text with pass 3 (bwt_seed_strategy1) jumping through the table (any K) is the text without it."""
+    k, bad = ctx.kat_kmer_table()
+    assert k >= 8 and bad == 0
+    fq, seqs = _reads(small_index, tmp_path, "kmer_tab", 800, 150, 10000, 2000, 2000, 78)
+    names, _, quals = bw.read_fastq(fq)
+    sams = {}
+    for K in (0, 3, 7, 16):
+        monkeypatch.setenv("BWAHIP_KMER_K", str(K))
+        with bw.Context(small_index["prefix"], 0) as c:
+            kk, bad = c.kat_kmer_table()
+            assert bad == 0 and kk == (0 if K == 0 else min(K, 11))
+            sams[K] = c.process_seqs(names, seqs, quals)
+            cnt = c.counters()
+            assert (cnt["pass3_jumped"] > 0) == (K >= 2)
+    assert sams[3] == sams[0] and sams[7] == sams[0] and sams[16] == sams[0]
+    assert ctx.process_seqs(names, seqs, quals) == sams[0]
+
+
 def test_extend_known_answers_vs_oracle_lib(ctx, small_index):
     """bwt_extend on the device for random walks (both directions), incl. size-1 intervals."""
     import ctypes as C
