@@ -410,7 +410,7 @@ def main():
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "read_len": rl, "paired": pe, "genome_mbp": args.genome_mbp, "genome_profile": args.genome_profile,
                        "stages": ctx.stage_names(),
                        "output": ctx.output_description(pe),
-                       "index_build_s": round(t_index, 1), "index_to_hbm_s": round(t_bcast, 2), "index_distribution": index_distribution, "host_cpus_usable": cpus},
+                       "index_in_hbm": ctx.index_footprint(), "index_build_s": round(t_index, 1), "index_to_hbm_s": round(t_bcast, 2), "index_distribution": index_distribution, "host_cpus_usable": cpus},
             "kernel_ms": {k: round(float(np.mean([x[k] for x in kms])), 3) for k in kms[0]},
             "launches_timed": n_launch, "sam_bytes_per_batch": sam_bytes,
             "per_read": per_read(counters, args.reads),
@@ -487,7 +487,8 @@ def other_kernels(km, counters, n_batches):
     sa_bytes = (64 * counters["lf"] + 8 * counters["sa"]) / n_batches
     return {
         "k_seeds": {"algorithmic_GBps": round(sa_bytes / (km["k_seeds"] * 1e-3) / 1e9, 1), "frac_of_peak": round(sa_bytes / (km["k_seeds"] * 1e-3) / 8e12, 4),
-                    "what": "64 B per LF step + 8 B per SA read (bwt_sa, bwt.c:86), counted by the kernel"},
+                    "what": "64 B per LF step + 8 B per SA read (bwt_sa, bwt.c:86), counted by the kernel; with the SA table kept for every row "
+                            "(index_in_hbm.sa_intv = 1) there are no LF steps left and the stage is three short launches (rows, look-up, contig ids)"},
         "k_extend": {"GCUPS": round(counters["cells"] / n_batches / ((km["k_extend"] + km["k_extend_spec"]) * 1e-3) / 1e9, 2),
                      "what": "ksw_extend2 cell updates per second (cells counted by the kernel, k_extend + k_extend_spec time)"},
     }

@@ -131,6 +131,7 @@ def lib():
     L.bwahip_kernel_name.restype = C.c_char_p
     L.bwahip_kat_introsort.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bwahip_kat_occ4.argtypes = [vp, C.c_int, vp, vp]
+    L.bwahip_index_footprint.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     L.bwahip_kat_sa.argtypes = [vp, C.c_int, vp, vp]
     L.bwahip_kat_kmer_table.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     L.bwahip_kat_extend.argtypes = [vp, C.c_int, vp, vp, vp]
@@ -414,6 +415,13 @@ class Context:
         out = np.zeros(len(k), dtype=np.uint64)
         _check(lib().bwahip_kat_sa(self._h, len(k), k.ctypes.data, out.ctypes.data), "bwahip_kat_sa")
         return out
+
+    def index_footprint(self):
+        """{'sa_intv', 'kmer_k', 'bwt_gb', 'sa_gb', 'pac_gb', 'interval_table_gb'} of the index in HBM (bwahip_index_footprint)."""
+        a, k, b = C.c_int(), C.c_int(), (C.c_uint64 * 4)()
+        _check(lib().bwahip_index_footprint(self._h, C.byref(a), C.byref(k), b), "bwahip_index_footprint")
+        return {"sa_intv": a.value, "kmer_k": k.value, "bwt_gb": round(b[0] / 1e9, 2), "sa_gb": round(b[1] / 1e9, 2), "pac_gb": round(b[2] / 1e9, 2),
+                "interval_table_gb": round(b[3] / 1e9, 2)}
 
     def kat_kmer_table(self):
         """(K, mismatches): the interval table against forward bwt_extend calls (bwahip_kat_kmer_table)."""

@@ -18,7 +18,7 @@ struct DevAnn { int64_t offset; int32_t len; int32_t is_alt; };
 
 // Everything a kernel needs to know about the index; passed by value as a kernel argument.
 struct DevIndex {
-	const uint4 *bwt;        // Occ-interleaved BWT viewed as 64-byte blocks = 4 x uint4 (bwt.h:74-75)
+	const uint4 *bwt;        // Occ-interleaved BWT viewed as 64-byte blocks = 4 x uint4 (bwt.h:74-75), the bases re-laid as bit planes (fmi_dev.h)
 	const uint64_t *sa;      // sampled SA, sa[0] = -1 (bwt.c:83)
 	const uint8_t *pac;      // forward strand, 4 bases/byte, MSB first (bntseq.c:229)
 	const DevAnn *anns;
@@ -141,6 +141,7 @@ struct SeedLaunch {
 	unsigned long long *counters;
 };
 int launch_seeds(const SeedLaunch &a, int64_t total_seeds, hipStream_t st);
+int launch_bwt_planes(uint32_t *bwt, uint64_t n_words, hipStream_t st);   // the bases of every Occ block from 2-bit codes to bit planes, in place
 int launch_sa_densify(const DevIndex &ix, uint64_t *dense, int to_intv, hipStream_t st);   // SA rows between the sampled ones, computed on the GPU
 
 struct BtNodeOpaque { int w[48]; };              // sizeof(BtNode) in k_chain.hip (2 + 11 + 12 ints, pad, 11 x int64)

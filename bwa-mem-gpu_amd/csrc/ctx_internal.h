@@ -94,6 +94,8 @@ struct bwahip_ctx {
 	HostIndex host = {};                 // host copy: contig table + packed reference (always owned); FM-index arrays only when loaded from files
 	DevIndex ix;
 	DevBuf d_bwt, d_sa, d_pac, d_anns;
+	DevBuf d_bwtp;                       // bit-plane copy of a caller-owned BWT (bwahip_init_device); otherwise d_bwt itself is re-laid in place
+	bool bwt_is_planes = false;          // d_bwt already holds the bit-plane layout (bwahip_ctx_clone_on: copied from a context's array)
 	DevBuf d_kmer;                       // the interval table of the BWT search (launch_kmer_table); clones read their source's
 	const bwahip_ctx *share_from = nullptr;   // bwahip_ctx_clone: the context whose index arrays this one reads
 	DevBuf d_sa_dense;                   // the SA table the kernels read when it is denser than the files' (launch_sa_densify); owned by the context that built it

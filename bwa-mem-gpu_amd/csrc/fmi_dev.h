@@ -1,6 +1,6 @@
 // Device-side FM-index primitives for gfx950.
 //
-// Work shape: one Occ block (64 B = 4 x u64 counts + 128 packed bases, bwt.h:74-75) is fetched by a
+// Work shape: one Occ block (64 B = 4 x u64 counts + 128 bases, bwt.h:74-75; the bases as bit planes, see count_bases64) is fetched by a
 // *quad* of 4 adjacent lanes, 16 B per lane (`global_load_dwordx4`), so every HBM request is one
 // fully used, naturally aligned 64-byte line.  Lanes 0/1 of the quad hold the four base counts,
 // lanes 2/3 hold 64 bases each and pop-count them; the partial results are combined with DPP
@@ -31,22 +31,28 @@ __device__ __forceinline__ uint64_t half_mirror64(uint64_t v)
 	return (uint64_t)half_mirror((uint32_t)v) | (uint64_t)half_mirror((uint32_t)(v >> 32)) << 32;
 }
 
-// Count, for each base c, the symbols equal to c among the first `n` (0..64) of the 64 bases held in
-// v (4 words, 16 bases each, first base in the top bits of v.x; bwt.h:80).  Returns 4 byte counters.
+// The 128 bases of a block IN HBM are kept as bit planes, not as bwa's 2-bit codes (k_bwt_planes re-lays them when the index is loaded; the
+// files stay bwa's): the third 16 bytes of a block = {H0, H1, L0, L1}, the fourth = {H2, H3, L2, L3}, where Hg / Lg hold the high / low bit of
+// the bases 32g .. 32g+31, first base in the top bit.  Counting the bases before a position is then a mask and three pop-counts per word pair
+// (both bits, high, low) instead of separating the planes of 2-bit codes at every look-up: a third of k_smem's vector instructions were that.
+//
+// Count, for each base c, the symbols equal to c among the first `n` (0..64) of the 64 bases held in v = {H0, H1, L0, L1}.  Returns 4 byte counters.
 __device__ __forceinline__ uint32_t count_bases64(uint4 v, int n)
 {
-	uint64_t hi01 = (uint64_t)v.x << 32 | v.y, hi23 = (uint64_t)v.z << 32 | v.w;   // 32 bases each, first base on top
-	int n0 = n < 32 ? n : 32, n1 = n - n0;
-	uint64_t m0 = n0 == 0 ? 0ull : ~0ull << ((32 - n0) << 1);
-	uint64_t m1 = n1 == 0 ? 0ull : ~0ull << ((32 - n1) << 1);
-	uint64_t a = hi01 & m0, b = hi23 & m1;
-	const uint64_t k5 = 0x5555555555555555ull;
-	uint64_t alo = a & k5, ahi = (a >> 1) & k5, blo = b & k5, bhi = (b >> 1) & k5;
-	uint32_t c3 = __popcll(ahi & alo) + __popcll(bhi & blo);
-	uint32_t c2 = __popcll(ahi & ~alo) + __popcll(bhi & ~blo);
-	uint32_t c1 = __popcll(~ahi & alo) + __popcll(~bhi & blo);
-	uint32_t c0 = (uint32_t)n - c1 - c2 - c3;
+	const int n0 = n < 32 ? n : 32, n1 = n - n0;
+	const uint32_t m0 = (uint32_t)(0xffffffff00000000ull >> n0), m1 = (uint32_t)(0xffffffff00000000ull >> n1);   // the top n0 / n1 bits
+	const uint32_t h0 = v.x & m0, h1 = v.y & m1, l0 = v.z & m0, l1 = v.w & m1;
+	const uint32_t c3 = __popc(h0 & l0) + __popc(h1 & l1);
+	const uint32_t ch = __popc(h0) + __popc(h1), cl = __popc(l0) + __popc(l1);
+	const uint32_t c2 = ch - c3, c1 = cl - c3, c0 = (uint32_t)n - ch - cl + c3;
 	return c0 | c1 << 8 | c2 << 16 | c3 << 24;
+}
+// the base at offset o (0..63) of the 64 bases held in v = {H0, H1, L0, L1}
+__device__ __forceinline__ uint32_t base_at64(uint4 v, int o)
+{
+	const uint32_t hw = o < 32 ? v.x : v.y, lw = o < 32 ? v.z : v.w;
+	const int bit = ~o & 31;
+	return (hw >> bit & 1) << 1 | (lw >> bit & 1);
 }
 
 // occ4 for one position per quad (bwt.c:169 bwt_occ4).  `p` must be uniform inside the quad.
@@ -281,10 +287,7 @@ __device__ __forceinline__ uint64_t lane_lf_count(const DevIndex &ix, uint64_t k
 {
 	const uint64_t pp = k - (k >= ix.primary);
 	const int o = (int)(pp & 127);
-	const uint4 h = o < 64 ? f.v2 : f.v3;
-	const int wi = o >> 4 & 3;
-	const uint32_t w = wi == 0 ? h.x : wi == 1 ? h.y : wi == 2 ? h.z : h.w;
-	const uint32_t c = w >> ((~o & 15) << 1) & 3;
+	const uint32_t c = base_at64(o < 64 ? f.v2 : f.v3, o & 63);
 	const uint32_t packed = count_bases64(f.v2, o + 1 < 64 ? o + 1 : 64) + count_bases64(f.v3, o + 1 > 64 ? o + 1 - 64 : 0);
 	const uint64_t c0 = (uint64_t)f.v0.y << 32 | f.v0.x, c1 = (uint64_t)f.v0.w << 32 | f.v0.z, c2 = (uint64_t)f.v1.y << 32 | f.v1.x, c3 = (uint64_t)f.v1.w << 32 | f.v1.z;
 	const uint64_t x = L2_at(ix, (int)c) + sel4((int)c, c0, c1, c2, c3) + (packed >> (c << 3) & 0xff);
@@ -304,9 +307,8 @@ __device__ __forceinline__ uint64_t quad_lf(const DevIndex &ix, uint64_t k)
 	uint64_t pp = k - (k >= ix.primary);                     // for k != primary identical to k - (k > primary)
 	uint4 v = ix.bwt[(pp >> 7) * 4 + r];
 	int o = (int)(pp & 127);                                 // symbol at offset o; occ counts bases 0..o
-	// the symbol: word (o>>4) of the 8 packed words; lane 2 has words 0-3, lane 3 words 4-7
-	uint32_t w = (o >> 4 & 3) == 0 ? v.x : (o >> 4 & 3) == 1 ? v.y : (o >> 4 & 3) == 2 ? v.z : v.w;
-	uint32_t sym = w >> ((~o & 15) << 1) & 3;
+	// the symbol: lane 2 has the planes of bases 0-63, lane 3 of 64-127
+	uint32_t sym = base_at64(v, o & 63);
 	uint32_t s2 = quad_bcast<2>(sym), s3 = quad_bcast<3>(sym);
 	uint32_t c = o < 64 ? s2 : s3;
 	int n = r == 2 ? (o + 1 < 64 ? o + 1 : 64) : r == 3 ? (o + 1 > 64 ? o + 1 - 64 : 0) : 0;

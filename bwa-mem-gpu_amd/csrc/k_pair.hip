@@ -135,28 +135,41 @@ __device__ __forceinline__ bool ms_window(const PairLaunch &a, const DevReg &an,
 
 constexpr int SW_TW = 1024;                                  // widest window k_matesw_sw takes (wider ones are aligned inside k_matesw)
 
-// per pair: copy both lists into their (larger) slots; list the pair for k_matesw if any anchor has an orientation left
-__global__ void k_pe_copy(PairLaunch a)
+// per pair: copy both lists into their (larger) slots; list the pair for k_matesw if any anchor has an orientation left.
+// W lanes work on the pair (1: a thread of k_pe_copy; 64: a wavefront of k_pe_copy_big, for the pairs with more than PE_COPY_SMALL regions --
+// 50 anchors x a list of thousands is 10^5 steps in a row for one thread, and a human-like batch has tens of thousands of such pairs)
+constexpr int PE_COPY_SMALL = 32;
+template <int W>
+__device__ __forceinline__ void pe_copy_pair(const PairLaunch &a, int p, int l)
 {
-	const int p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= a.n_reads >> 1) return;
 	bool need = false;
+	int failed = 0;
+	for (int d = 0; d < 4; ++d) failed |= a.pes[d].failed ? 1 << d : 0;
 	for (int i = 0; i < 2; ++i) {
 		const int r = p << 1 | i, n = a.reg_n[r];
 		const DevReg *src = a.regs + a.reg_base[r];
 		DevReg *dst = a.pe_regs + a.pe_base[r];
-		for (int j = 0; j < n; ++j) dst[j] = src[j];
-		a.pe_n[r] = n;
+		for (int j = l; j < n; j += W) dst[j] = src[j];
+		if (l == 0) a.pe_n[r] = n;
 		const int m = r ^ 1;
 		const DevReg *ma = a.regs + a.reg_base[m];
+		const int n_m = a.reg_n[m];
 		const int l_ms = (int)(a.off[m + 1] - a.off[m]);
 		for (int j = 0; j < a.nb[r]; ++j) {
-			const int sk = skip_mask_seq(a, src[j].rb, ma, a.reg_n[m]);
+			// skip mask of mem_matesw (bwamem_pair.c:143-150): the orientations in which the mate already has a hit at a proper distance
+			const int64_t arb = src[j].rb;
+			int sk = failed;
+			for (int k = l; k < n_m; k += W) {
+				int64_t dist;
+				const int d = infer_dir(a.ix.l_pac, arb, ma[k].rb, &dist);
+				if (dist >= a.pes[d].low && dist <= a.pes[d].high) sk |= 1 << d;
+			}
+			if (W > 1) sk = (__ballot(sk & 1) ? 1 : 0) | (__ballot(sk & 2) ? 2 : 0) | (__ballot(sk & 4) ? 4 : 0) | (__ballot(sk & 8) ? 8 : 0);
 			if (sk == 15) continue;
 			need = true;
 			// the alignments this anchor asks for against the unrescued list can be done ahead, in parallel (k_matesw_sw)
 			if (l_ms * a.opt.a < 250)
-				for (int o = 0; o < 4; ++o) {
+				for (int o = W > 1 ? l : 0; o < 4; o += W > 1 ? 64 : 1) {
 					int64_t rb, re;
 					if ((sk >> o & 1) || !ms_window(a, src[j], o, l_ms, rb, re) || re - rb > SW_TW) continue;
 					const int slot = (int)a.sw_base[r] + 4 * j + o;
@@ -166,7 +179,21 @@ __global__ void k_pe_copy(PairLaunch a)
 				}
 		}
 	}
-	if (need) { a.resc_list[atomicAdd(a.resc_n, 1)] = p; a.resc_flag[p] = 1; }
+	if (need && l == 0) { a.resc_list[atomicAdd(a.resc_n, 1)] = p; a.resc_flag[p] = 1; }
+}
+__global__ void k_pe_copy(PairLaunch a)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= a.n_reads >> 1) return;
+	if (a.reg_n[p << 1] + a.reg_n[p << 1 | 1] > PE_COPY_SMALL) return;     // k_pe_copy_big's
+	pe_copy_pair<1>(a, p, 0);
+}
+__global__ __launch_bounds__(256) void k_pe_copy_big(PairLaunch a)
+{
+	const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (p >= a.n_reads >> 1) return;
+	if (a.reg_n[p << 1] + a.reg_n[p << 1 | 1] <= PE_COPY_SMALL) return;
+	pe_copy_pair<64>(a, p, lane());
 }
 
 // ---------------------------------------------------------------------------------------------------- mem_matesw
@@ -791,6 +818,7 @@ int launch_pe_copy(const PairLaunch &a, hipStream_t st)
 	const int np = a.n_reads >> 1;
 	if (np <= 0) return 0;
 	hipLaunchKernelGGL(k_pe_copy, dim3((np + 255) / 256), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(k_pe_copy_big, dim3((np + 3) / 4), dim3(256), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st)

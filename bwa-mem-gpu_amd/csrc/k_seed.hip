@@ -135,6 +135,30 @@ __global__ __launch_bounds__(256) void k_seed_rid(SeedLaunch a, long long total)
 	a.seeds[sid].rid = dev_intv2rid(a.ix, rbeg, rbeg + a.seeds[sid].len);
 }
 
+// ------------------------------------------------------------- the bases of the Occ blocks as bit planes (fmi_dev.h: count_bases64)
+__device__ __forceinline__ uint32_t even_bits16(uint32_t x)   // bits 30, 28, .. 0 of x -> bits 15 .. 0
+{
+	x &= 0x55555555u;
+	x = (x | x >> 1) & 0x33333333u; x = (x | x >> 2) & 0x0f0f0f0fu; x = (x | x >> 4) & 0x00ff00ffu; x = (x | x >> 8) & 0x0000ffffu;
+	return x;
+}
+// words 8..15 of every 16-word block: eight words of sixteen 2-bit codes (first base on top, bwt.h:80) -> {H0,H1,L0,L1, H2,H3,L2,L3}
+__global__ __launch_bounds__(256) void k_bwt_planes(uint32_t *bwt, uint64_t n_blocks)
+{
+	for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+		uint4 *p = reinterpret_cast<uint4*>(bwt + b * 16 + 8);
+		const uint4 lo = p[0], hi = p[1];
+		const uint32_t w[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+		uint32_t H[4], L[4];
+		for (int g = 0; g < 4; ++g) {
+			H[g] = even_bits16(w[2 * g] >> 1) << 16 | even_bits16(w[2 * g + 1] >> 1);
+			L[g] = even_bits16(w[2 * g]) << 16 | even_bits16(w[2 * g + 1]);
+		}
+		p[0] = make_uint4(H[0], H[1], L[0], L[1]);
+		p[1] = make_uint4(H[2], H[3], L[2], L[3]);
+	}
+}
+
 // ------------------------------------------------------------- the suffix array, denser than the index files hold it
 // bwa index keeps SA[k] for every 32nd BWT row k and bwt_sa (bwt.c:86) walks LF steps from a row to the next sampled one: 31 dependent 64-byte
 // gathers per look-up on average (a step lands on a sampled row with probability 1/32), 290 per read -- 8 ms per 1 M-read batch, a quarter of
@@ -201,6 +225,12 @@ int launch_seeds(const SeedLaunch &a, int64_t total, hipStream_t st)
 	if (walks >= 2) hipLaunchKernelGGL(k_seed_walk<2>, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
 	else hipLaunchKernelGGL(k_seed_walk<1>, dim3((unsigned)blocks), dim3(256), 0, st, a, (long long)total);
 	hipLaunchKernelGGL(k_seed_rid, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, (long long)total);
+	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
+}
+int launch_bwt_planes(uint32_t *bwt, uint64_t n_words, hipStream_t st)
+{
+	const uint64_t n_blocks = n_words / 16;
+	if (n_blocks) hipLaunchKernelGGL(k_bwt_planes, dim3(256 * 16), dim3(256), 0, st, bwt, n_blocks);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 // dense must hold (seq_len >> log2(to_intv)) + 1 entries; ix.sa / ix.sa_intv are the table of the index files

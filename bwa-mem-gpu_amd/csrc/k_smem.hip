@@ -299,14 +299,18 @@ __global__ __launch_bounds__(256, 4) void k_smem(SmemLaunch a)
 					}
 					if (!started) st = ST_FINISH;                  // pass 3 is k_smem3's
 				}
-			} else if (st == ST_FWD) {
+			}
+			// (no `else`: a start falls through to its first forward step, the end of the forward phase to the first backward one, in the same
+			// turn -- the wavefront takes as many turns as its slowest lane has transitions)
+			if (st == ST_FWD) {
 				const int bq = i < len ? QB(i) : 4;
 				if (bq < 4) { need = true; is_back = 0; req = ik; cb = 3 - bq; }
 				else {                                           // end of read / ambiguous base (bwt.c:316-320)
 					FWD_PUSH(ik.x0, ik.x1, ik.x2, ik_end); last_push_end = ik_end;
 					FWD_FINISH();
 				}
-			} else if (st == ST_BWD) {
+			}
+			if (st == ST_BWD && !need) {
 				if (c < 0) {                                     // read start or ambiguous base: every prev[] ends here
 					for (int jj = 0; jj < prev_n; ++jj) {
 						uint64_t x0, x1, x2, info;
@@ -592,7 +596,8 @@ __global__ __launch_bounds__(256) void k_smem3(SmemLaunch a)
 						i = x + kj; st = P_EXT;
 					} else x = x + m < len ? x + m + 1 : len;        // an ambiguous base or the read's end comes first: bwt.c:376-378
 				}
-			} else {
+			}
+			if (st == P_EXT) {                                    // (no `else`: a start goes on to its first extension in the same turn)
 				const int bq = i < len ? qbase(qrow, i, qw, qwi) : 4;
 				if (bq < 4) { need = true; cb = 3 - bq; }
 				else { x = i < len ? i + 1 : len; st = P_SCAN; }   // bwt.c:376-378

@@ -193,6 +193,19 @@ int ctx_setup(bwahip_ctx *c, const bwahip_bwt_t *bwt, const bwahip_bns_t *bns, c
 	for (ix.sa_shift = 0; (1 << ix.sa_shift) < bwt->sa_intv; ++ix.sa_shift);
 	if ((1 << ix.sa_shift) != bwt->sa_intv) return BWAHIP_EINVAL;
 	if (bwt->bwt_size < ((bwt->seq_len + 127) / 128) * 16) return BWAHIP_EINVAL;   // every 128-base block must be present
+	// the bases of every Occ block as bit planes (fmi_dev.h): in place in the context's own array; a caller-owned array (bwahip_init_device)
+	// is left as it is and a copy re-laid; a clone reads its source's array
+	if (!c->share_from && !c->bwt_is_planes) {
+		uint32_t *words = (uint32_t*)c->d_bwt.p;
+		if (c->external_index) {
+			if ((rc = c->d_bwtp.ensure((size_t)bwt->bwt_size * 4))) return rc;
+			HIP_TRY(hipMemcpyAsync(c->d_bwtp.p, bwt->bwt, (size_t)bwt->bwt_size * 4, hipMemcpyDeviceToDevice, c->stream));
+			words = (uint32_t*)c->d_bwtp.p;
+			ix.bwt = c->d_bwtp.as<uint4>();
+		}
+		if ((rc = launch_bwt_planes(words, bwt->bwt_size, c->stream))) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
 	// the SA table of the kernels: every row (or every sa_intv-th), filled in on the GPU from the files' every 32nd (k_seed.hip)
 	int want = c->knobs.sa_intv < 1 ? 1 : c->knobs.sa_intv;
 	while (want & (want - 1)) want &= want - 1;
@@ -278,7 +291,7 @@ int bwahip_ctx_clone(bwahip_ctx *src, bwahip_ctx **out)
 {
 	if (!src || !out || !src->d_bwt.p || !src->d_sa.p || !src->d_pac.p) return BWAHIP_EINVAL;
 	bwahip_bwt_t b = src->host.bwt;
-	b.bwt = (uint32_t*)src->d_bwt.p;
+	b.bwt = (uint32_t*)const_cast<uint4*>(src->ix.bwt);       // (bit planes already: share_from tells ctx_setup)
 	b.sa = const_cast<uint64_t*>(src->ix.sa); b.sa_intv = src->ix.sa_intv; b.n_sa = src->ix.n_sa;   // the table src's kernels read (the dense one when src built it)
 	int rc = init_device_impl(&b, &src->host.bns, (const uint8_t*)src->d_pac.p, src->device, out, src);
 	if (rc) return rc;
@@ -296,7 +309,7 @@ int bwahip_ctx_clone_on(bwahip_ctx *src, int device, bwahip_ctx **out)
 	int n_dev = 0;
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) { fprintf(stderr, "[bwahip] no usable HIP device (requested %d of %d)\n", device, n_dev); return BWAHIP_ENODEV; }
 	bwahip_ctx *c = new bwahip_ctx();
-	c->device = device; c->index_resident = true;
+	c->device = device; c->index_resident = true; c->bwt_is_planes = true;
 	const size_t n_bwt = (size_t)src->host.bwt.bwt_size * 4, n_sa = (size_t)src->host.bwt.n_sa * 8, n_pac = (size_t)src->host.bns.l_pac / 4 + 1;
 	int rc = bwahip_copy_host_index(&src->host.bwt, &src->host.bns, src->host.pac, &c->host);
 	if (!rc && hipSetDevice(device) != hipSuccess) rc = BWAHIP_ENODEV;
@@ -307,7 +320,7 @@ int bwahip_ctx_clone_on(bwahip_ctx *src, int device, bwahip_ctx **out)
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src->device, 0);   // already enabled is fine
 		(void)hipGetLastError();
-		if (hipMemcpyPeer(c->d_bwt.p, device, src->d_bwt.p, src->device, n_bwt) != hipSuccess || hipMemcpyPeer(c->d_sa.p, device, src->d_sa.p, src->device, n_sa) != hipSuccess ||
+		if (hipMemcpyPeer(c->d_bwt.p, device, src->ix.bwt, src->device, n_bwt) != hipSuccess || hipMemcpyPeer(c->d_sa.p, device, src->d_sa.p, src->device, n_sa) != hipSuccess ||
 		    hipMemcpyPeer(c->d_pac.p, device, src->d_pac.p, src->device, n_pac) != hipSuccess) { fprintf(stderr, "[bwahip] device-to-device copy of the index failed: %s\n", hipGetErrorString(hipGetLastError())); rc = BWAHIP_ENODEV; }
 	}
 	if (!rc) rc = ctx_setup(c, &c->host.bwt, &c->host.bns, c->host.pac);
@@ -339,7 +352,7 @@ void bwahip_destroy(bwahip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_sa_dense, &c->d_kmer, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwtp, &c->d_sa, &c->d_sa_dense, &c->d_kmer, &c->d_pac, &c->d_anns, &c->d_seq, &c->d_off, &c->d_seq4, &c->d_smem_heavy, &c->d_raw, &c->d_raw_n, &c->d_intv, &c->d_intv_n, &c->d_seed_cnt,
 	                   &c->d_lrep, &c->d_seed_base, &c->d_seeds, &c->d_scratch, &c->d_misc,
 	                   &c->d_cw, &c->d_nxt, &c->d_ord, &c->d_wts, &c->d_kept, &c->d_first, &c->d_keep, &c->d_nodes, &c->d_stack,
 	                   &c->d_chains, &c->d_chain_seeds, &c->d_chain_n, &c->d_kept_seeds, &c->d_reg_base, &c->d_regs, &c->d_tmp_regs,
@@ -474,6 +487,20 @@ int bwahip_kat_sa(bwahip_ctx *c, int n, const uint64_t *k, uint64_t *out)
 	if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BWAHIP_ENODEV;
 	dk.release(); dout.release();
 	return rc;
+}
+
+int bwahip_index_footprint(bwahip_ctx *c, int *sa_intv, int *kmer_k, uint64_t *bytes4)
+{
+	if (!c) return BWAHIP_EINVAL;
+	if (sa_intv) *sa_intv = c->ix.sa_intv;
+	if (kmer_k) *kmer_k = c->ix.kmer_k;
+	if (bytes4) {
+		bytes4[0] = (uint64_t)c->host.bwt.bwt_size * 4;                       // Occ-interleaved BWT
+		bytes4[1] = (uint64_t)c->ix.n_sa * 8;                                  // the SA table the kernels read
+		bytes4[2] = (uint64_t)c->host.bns.l_pac / 4 + 1;                       // packed reference
+		bytes4[3] = c->ix.kmer_k ? (kmer_off(c->ix.kmer_k + 1) + 4) * 16 : 0;  // interval table
+	}
+	return 0;
 }
 
 int bwahip_kat_kmer_table(bwahip_ctx *c, int *k_out, uint64_t *bad_out)

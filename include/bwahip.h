@@ -317,6 +317,10 @@ int bwahip_batch_counters(bwahip_ctx *ctx, uint64_t *counters, int n);
 
 /* Known-answer helpers used by the parity tests: device Occ/extend/SA on arrays of inputs. */
 int bwahip_kat_occ4(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *cnt4_out);
+/* What the index occupies in HBM: interval of the SA table the kernels read (1 = every BWT row; the index files hold every 32nd, bwt.c:86
+ * walks the rest), longest string of the interval table (0: none), and the bytes of {BWT with Occ counts, SA table, packed reference,
+ * interval table}.  Tunables: BWAHIP_SA_INTV, BWAHIP_KMER_K. */
+int bwahip_index_footprint(bwahip_ctx *ctx, int *sa_intv, int *kmer_k, uint64_t *bytes4);
 int bwahip_kat_sa(bwahip_ctx *ctx, int n, const uint64_t *k, uint64_t *sa_out);
 /* The interval table of the BWT search (strings of up to *k_out bases): every entry of every length against bwt_extend (bwt.c:262) run
  * FORWARD from the entry of the string without its last base (the table itself is filled by backward extensions); *bad_out = mismatches. */
