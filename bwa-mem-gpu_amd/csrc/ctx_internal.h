@@ -115,6 +115,7 @@ struct bwahip_ctx {
 	DevBuf d_fregs, d_fregs2, d_fscr, d_need, d_xa_owner, d_freg_n, d_npri, d_task_n, d_rec_n, d_task_base, d_tasks, d_aln_of_reg, d_alns;
 	DevBuf d_hist, d_pair_tab, d_nb, d_pe_cap, d_pe_base, d_pe_regs, d_pe_n, d_pe_tmp, d_pe_keys, d_pe_idx, d_resc, d_ms_slab, d_pe_read, d_sw_cnt, d_sw_base, d_sw_res, d_sw_tasks, d_sw_info;   // paired-end stages
 	bwahip_pestat_t last_pes[4];         // insert-size statistics of the last paired-end batch
+	unsigned long long last_sw_tasks = 0;   // alignments k_matesw_sw ran ahead of the list logic (BWAHIP_PE_LOG)
 	unsigned long long last_pe_counters[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // mate-rescue alignments run / regions added / most per pair / pairs rescued
 	DevBuf d_task_lists;                 // k_cigar's two work lists (no-DP tasks, DP tasks)
 	DevBuf d_resc_flag;                  // one byte per pair: mate rescue works on it (finalised by the second k_mark / k_pair launch)

@@ -162,6 +162,7 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	n_resc_out = n_resc;
 	c->last_pe_counters[3] = (unsigned long long)n_resc;
+	c->last_sw_tasks = (unsigned long long)n_sw_tasks;
 	if (n_resc > 0 || n_sw_tasks > 0) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
 		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -582,8 +583,8 @@ extern "C" int bwahip_last_pe_stats(bwahip_ctx *ctx, bwahip_pestat_t *pes4, uint
 	if (counters2) for (int i = 0; i < 4; ++i) counters2[i] = ctx->last_pe_counters[i];
 	if (getenv("BWAHIP_PE_LOG")) {
 		const unsigned long long *c = ctx->last_pe_counters;
-		fprintf(stderr, "[bwahip] mate rescue: %llu alignments (%llu inside k_matesw), %llu regions added, %llu pairs; k_matesw summed over its wavefronts: window fetch %.1f ms, alignments %.1f ms, list clean-up %.1f ms; longest pair %.2f ms\n",
-		        c[0], c[8], c[1], c[3], c[4] / 1e5, c[5] / 1e5, c[6] / 1e5, c[7] / 1e5);
+		fprintf(stderr, "[bwahip] mate rescue: %llu alignments run ahead by k_matesw_sw; mem_matesw used %llu (%llu more inside k_matesw), %llu regions added, %llu pairs; k_matesw summed over its wavefronts: window fetch %.1f ms, alignments %.1f ms, list clean-up %.1f ms; longest pair %.2f ms\n",
+		        ctx->last_sw_tasks, c[0], c[8], c[1], c[3], c[4] / 1e5, c[5] / 1e5, c[6] / 1e5, c[7] / 1e5);
 	}
 	return 0;
 }
