@@ -449,6 +449,10 @@ def main():
         parity_ok = None
         if not args.no_cpu_baseline and world == 1:               # rank 0 at N = 1 only
             n_s = min(args.cpu_sample, args.reads)
+            if pe and n_s < min(args.batch, args.reads):
+                # paired-end: mem_pestat is per batch, so a part of a batch is not the same problem (other insert-size bounds, other rescues)
+                log(f"cpu sample raised from {n_s} to one whole batch ({min(args.batch, args.reads)} reads): paired-end parity needs the batch's own insert-size estimate")
+                n_s = min(args.batch, args.reads)
             n_s = max(args.batch, n_s // args.batch * args.batch) if n_s >= args.batch else n_s & (~1 if pe else ~0)   # whole batches: the same -K cuts on both sides
             out["cpu_baseline"], sam_cpu_path = cpu_baseline(tp, prefix, reads[:n_s], pe, cpus, workdir, K_bases)
             if sam_cpu_path:
