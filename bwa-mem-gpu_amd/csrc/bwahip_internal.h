@@ -302,7 +302,7 @@ int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
 int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
 int launch_resc_order(const PairLaunch &a, int n_resc, int *scratch, hipStream_t st);   // rescue list by list length, longest first (scratch: 3 n_resc + 8 ints)
-int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st);
+int launch_matesw_sw(const PairLaunch &a, int n_tasks, int max_len, hipStream_t st);   // max_len: longest read of the batch
 int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st);   // subset 2: n_listed pairs of resc_list
 size_t matesw_slab_bytes(int64_t window);
 int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st, int read_lo = 0, int read_hi = -1);

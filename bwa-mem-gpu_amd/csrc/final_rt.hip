@@ -166,7 +166,7 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	if (n_resc > 0 || n_sw_tasks > 0) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
 		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-		if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->stream2))) return rc;   // the alignments against the unrescued lists, all at once
+		if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->max_len, c->stream2))) return rc;   // the alignments against the unrescued lists, all at once
 		if (n_resc > 0) {
 			if ((rc = c->d_resc_ord.ensure(((size_t)3 * n_resc + 8) * 4)) || (rc = launch_resc_order(pl, n_resc, c->d_resc_ord.as<int>(), c->stream2))) return rc;
 			const int grid = std::min(n_resc, 2048);

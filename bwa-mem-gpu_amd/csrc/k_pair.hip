@@ -398,13 +398,16 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 // The alignments k_pe_copy queued: one per 16-lane group, four per wavefront, byte kernel, cells in registers.  A single
 // alignment is a chain of ~1 500 dependent cycles per reference base; what this kernel buys is that the (up to dozens of)
 // alignments of one pair, which mem_matesw runs one after the other, proceed side by side.
+// QMAX: longest mate the instantiation takes (160: ten cells per lane; 256: sixteen).  LDS decides how many alignments a CU holds: column maxima
+// as bytes and arrays sized for 160 bases make it 11.9 KB per workgroup = 3 wavefronts per SIMD (18.4 KB, 2 wavefronts with the general sizes).
+template <int QMAX>
 __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 {
 	__shared__ int8_t s_mat[32];
 	__shared__ uint8_t s_tw[4][SW_TW];
-	__shared__ uint16_t s_cm[4][SW_TW];
-	__shared__ uint8_t s_q[4][256];
-	__shared__ int8_t s_prof[4][5 * 256];
+	__shared__ uint8_t s_cm[4][SW_TW];
+	__shared__ uint8_t s_q[4][QMAX];
+	__shared__ int8_t s_prof[4][5 * QMAX];
 	const int lane_ = lane(), g = lane_ >> 4, gl = lane_ & 15;
 	if (lane_ < 25) s_mat[lane_] = a.opt.mat[lane_];
 	__syncthreads();
@@ -426,10 +429,10 @@ __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 	else for (int i = gl; i < l_ms; i += 16) s_q[g][i] = ms[i];
 	__threadfence_block();
 	ssw::Work w;
-	w.prof = s_prof[g]; w.H0 = w.H1 = w.E = w.Hmax = nullptr; w.colmax = s_cm[g];
+	w.prof = s_prof[g]; w.H0 = w.H1 = w.E = w.Hmax = nullptr; w.colmax = nullptr; w.colmax8 = s_cm[g];
 	const int xtra = ssw::XSUBO | ssw::XSTART | ssw::XBYTE | (a.opt.min_seed_len * a.opt.a);
 	ssw::Res aln;
-	if (l_ms <= 160) aln = ssw::align2<16, 10>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
+	if (QMAX <= 160 || l_ms <= 160) aln = ssw::align2<16, 10>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
 	else aln = ssw::align2<16, 16>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
 	if (gl == 0) { SwRes o_ = { 2, aln.score, aln.te, aln.qe, aln.score2, aln.te2, aln.tb, aln.qb }; a.sw_res[slot] = o_; }
 }
@@ -830,10 +833,11 @@ int launch_matesw(const PairLaunch &a, int grid, hipStream_t st)
 	hipLaunchKernelGGL((k_matesw<8, false>), dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
-int launch_matesw_sw(const PairLaunch &a, int n_tasks, hipStream_t st)
+int launch_matesw_sw(const PairLaunch &a, int n_tasks, int max_len, hipStream_t st)
 {
 	if (n_tasks <= 0) return 0;
-	hipLaunchKernelGGL(k_matesw_sw, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
+	if (max_len <= 160) hipLaunchKernelGGL(k_matesw_sw<160>, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL(k_matesw_sw<256>, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st)

@@ -20,7 +20,7 @@ enum { XBYTE = 0x10000, XSTOP = 0x20000, XSUBO = 0x40000, XSTART = 0x80000 };   
 // LDS (or global) working set of one group.  prof: 5 rows of slen*P scores (ksw_qinit, ksw.c:60-110): bytes for P = 16
 // (score + shift), signed bytes for P = 8.  H0/H1/E/Hmax: slen*P 16-bit cells each.  colmax: one entry per target
 // column (only read when a second-best score is asked for).
-struct Work { int8_t *prof; int16_t *H0, *H1, *E, *Hmax; uint16_t *colmax; };
+struct Work { int8_t *prof; int16_t *H0, *H1, *E, *Hmax; uint16_t *colmax; uint8_t *colmax8 = nullptr; };   // colmax8: the column maxima as bytes (byte kernel only: they are <= 255) instead of colmax
 __host__ __device__ constexpr size_t work_bytes(int P, int qlen_max) { return (size_t)((qlen_max + P - 1) / P) * P * (5 + 4 * 2); }
 
 template <int P> __device__ __forceinline__ int gl_of(int lane) { return lane & (P - 1); }
@@ -127,7 +127,7 @@ __device__ __forceinline__ Res pass(const Work &w, int lane, int slen, int shift
 			if (stop) break;
 		}
 		const int imax = group_max<P>(mxv);
-		if (w.colmax && gl == 0) w.colmax[i] = (uint16_t)imax;
+		if (gl == 0) { if (w.colmax8) w.colmax8[i] = (uint8_t)imax; else if (w.colmax) w.colmax[i] = (uint16_t)imax; }
 		n_cols = i + 1;
 		if (imax > gmax) {
 			gmax = imax; te = i;
@@ -150,7 +150,7 @@ __device__ __forceinline__ Res pass(const Work &w, int lane, int slen, int shift
 			qe = group_min<P>(qe);
 			r.qe = slen > 0 ? qe : -1;
 		}
-		if (minsc < 0x10000 && w.colmax) {
+		if (minsc < 0x10000 && (w.colmax || w.colmax8)) {
 			// the b[] list of ksw.c:194-204 replayed from the column maxima, then the scan of ksw.c:217-225; every lane
 			// of the group runs it (same values everywhere)
 			__threadfence_block();                                    // colmax was written by lane 0 of the group
@@ -158,7 +158,7 @@ __device__ __forceinline__ Res pass(const Work &w, int lane, int slen, int shift
 			int cur_m = -1, cur_i = -1;
 			bool have = false;
 			for (int i = 0; i < n_cols; ++i) {
-				const int m = w.colmax[i];
+				const int m = w.colmax8 ? (int)w.colmax8[i] : (int)w.colmax[i];
 				if (m < minsc) continue;
 				if (!have || cur_i + 1 != i) {
 					if (have && (cur_i < low || cur_i > high) && cur_m > r.score2) { r.score2 = cur_m; r.te2 = cur_i; }
@@ -189,11 +189,21 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 #pragma unroll
 	for (int j = 0; j < SLEN; ++j) { H[j] = 0; E[j] = 0; Hm[j] = 0; }
 	int gmax = 0, te = -1, n_cols = 0;
-	for (int i = 0; i < tlen; ++i) {
-		const int8_t *S = w.prof + (size_t)t.at(i) * slen * P;
-		int sv[SLEN];
+	// the profile row of column i + 1 is fetched while column i is computed: the byte loads may alias the column-maximum store at the end of
+	// a column as far as the compiler knows, so left to it every column began with two dependent LDS round trips (base, then its row)
+	int sv[SLEN];
+	{
+		const int8_t *S = w.prof + (size_t)(tlen > 0 ? t.at(0) : 0) * slen * P;
 #pragma unroll
 		for (int j = 0; j < SLEN; ++j) sv[j] = j < slen ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
+	}
+	for (int i = 0; i < tlen; ++i) {
+		int svn[SLEN];
+		{
+			const int8_t *S = w.prof + (size_t)t.at(i + 1 < tlen ? i + 1 : i) * slen * P;
+#pragma unroll
+			for (int j = 0; j < SLEN; ++j) svn[j] = j < slen ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
+		}
 		int f = 0, mxv = 0, last = 0;
 #pragma unroll
 		for (int j = 0; j < SLEN; ++j) if (j == slen - 1) last = H[j];
@@ -234,7 +244,7 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 			}
 		}
 		const int imax = group_max<P>(mxv);
-		if (w.colmax && gl == 0) w.colmax[i] = (uint16_t)imax;
+		if (gl == 0) { if (w.colmax8) w.colmax8[i] = (uint8_t)imax; else if (w.colmax) w.colmax[i] = (uint16_t)imax; }
 		n_cols = i + 1;
 		if (imax > gmax) {
 			gmax = imax; te = i;
@@ -242,6 +252,8 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 			for (int j = 0; j < SLEN; ++j) Hm[j] = H[j];
 			if (is8 ? (gmax + shift >= 255 || gmax >= endsc) : gmax >= endsc) break;
 		}
+#pragma unroll
+		for (int j = 0; j < SLEN; ++j) sv[j] = svn[j];
 	}
 	Res r = { 0, -1, -1, -1, -1, -1, -1 };
 	r.score = is8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
@@ -256,13 +268,13 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 		for (int j = 0; j < SLEN; ++j) if (j < slen && (Hm[j] & 0xffff) == best) { const int k = j + gl * slen; qe = qe < k ? qe : k; }
 		qe = group_min<P>(qe);
 		r.qe = slen > 0 ? qe : -1;
-		if (minsc < 0x10000 && w.colmax) {
+		if (minsc < 0x10000 && (w.colmax || w.colmax8)) {
 			__threadfence_block();
 			const int span = (r.score + qmax - 1) / qmax, low = te - span, high = te + span;
 			int cur_m = -1, cur_i = -1;
 			bool have = false;
 			for (int i = 0; i < n_cols; ++i) {
-				const int m = w.colmax[i];
+				const int m = w.colmax8 ? (int)w.colmax8[i] : (int)w.colmax[i];
 				if (m < minsc) continue;
 				if (!have || cur_i + 1 != i) {
 					if (have && (cur_i < low || cur_i > high) && cur_m > r.score2) { r.score2 = cur_m; r.te2 = cur_i; }
@@ -294,7 +306,7 @@ __device__ __forceinline__ Res align2(const Work &w, int lane, int qlen, const u
 	if (P == 16 && r.score == 255) return r;                      // qe unknown: the reference reads out of bounds here; unreachable (score <= qlen*a < 250)
 	// second pass on the reversed prefixes to find the start (ksw.c:356-363); it scans tlen columns, not te+1
 	qv.rev_n = r.qe + 1; tv.rev_n = r.te + 1;
-	Work w2 = w; w2.colmax = nullptr;
+	Work w2 = w; w2.colmax = nullptr; w2.colmax8 = nullptr;
 	qinit<P>(w2, gl, r.qe + 1, qv, mat, slen, shift, qmax);
 	const Res rr = in_regs ? pass_reg<P, SLEN ? SLEN : 1>(w2, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, 0x10000, r.score & 0xffff)
 	                       : pass<P, true>(w2, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, 0x10000, r.score & 0xffff);
