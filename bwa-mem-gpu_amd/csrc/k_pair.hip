@@ -399,12 +399,12 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 // alignment is a chain of ~1 500 dependent cycles per reference base; what this kernel buys is that the (up to dozens of)
 // alignments of one pair, which mem_matesw runs one after the other, proceed side by side.
 // QMAX: longest mate the instantiation takes (160: ten cells per lane; 256: sixteen).  LDS decides how many alignments a CU holds: column maxima
-// as bytes and arrays sized for 160 bases make it 11.9 KB per workgroup = 3 wavefronts per SIMD (18.4 KB, 2 wavefronts with the general sizes).
+// as bytes, the window two bases per byte and arrays sized for 160 bases make it 9.8 KB per workgroup = 4 wavefronts per SIMD (18.4 KB, 2 wavefronts with bytes, 16-bit maxima and the general sizes).
 template <int QMAX>
 __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 {
 	__shared__ int8_t s_mat[32];
-	__shared__ uint8_t s_tw[4][SW_TW];
+	__shared__ uint8_t s_tw[4][SW_TW / 2];                       // the reference window, two bases per byte
 	__shared__ uint8_t s_cm[4][SW_TW];
 	__shared__ uint8_t s_q[4][QMAX];
 	__shared__ int8_t s_prof[4][5 * QMAX];
@@ -424,7 +424,8 @@ __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 	ms_window(a, an, o, l_ms, rb, re);                            // eligibility was established by k_pe_copy
 	const int tlen = (int)(re - rb);
 	const int is_rev = (o >> 1) != (o & 1);
-	for (int i = gl; i < tlen; i += 16) s_tw[g][i] = (uint8_t)ref_base(a.ix, rb + i);
+	for (int i = gl; 2 * i < tlen; i += 16)
+		s_tw[g][i] = (uint8_t)(ref_base(a.ix, rb + 2 * i) | (2 * i + 1 < tlen ? ref_base(a.ix, rb + 2 * i + 1) : 0) << 4);
 	if (is_rev) for (int i = gl; i < l_ms; i += 16) { const uint8_t c = ms[i]; s_q[g][l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
 	else for (int i = gl; i < l_ms; i += 16) s_q[g][i] = ms[i];
 	__threadfence_block();
@@ -432,8 +433,8 @@ __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 	w.prof = s_prof[g]; w.H0 = w.H1 = w.E = w.Hmax = nullptr; w.colmax = nullptr; w.colmax8 = s_cm[g];
 	const int xtra = ssw::XSUBO | ssw::XSTART | ssw::XBYTE | (a.opt.min_seed_len * a.opt.a);
 	ssw::Res aln;
-	if (QMAX <= 160 || l_ms <= 160) aln = ssw::align2<16, 10>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
-	else aln = ssw::align2<16, 16>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra);
+	if (QMAX <= 160 || l_ms <= 160) aln = ssw::align2<16, 10>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra, true);
+	else aln = ssw::align2<16, 16>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra, true);
 	if (gl == 0) { SwRes o_ = { 2, aln.score, aln.te, aln.qe, aln.score2, aln.te2, aln.tb, aln.qb }; a.sw_res[slot] = o_; }
 }
 

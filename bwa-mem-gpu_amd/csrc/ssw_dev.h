@@ -54,8 +54,13 @@ __device__ __forceinline__ int sat_sub_u(int a, int b) { const int s = a - b; re
 // Sequence access: element i of a byte string read with a stride, optionally with its first `rev_n` elements reversed
 // (revseq of ksw.c:358 on a prefix, the rest untouched).
 struct SeqView {
-	const uint8_t *p; int stride, rev_n;
-	__device__ __forceinline__ int at(int i) const { return p[(i < rev_n ? rev_n - 1 - i : i) * stride]; }
+	const uint8_t *p; int stride, rev_n; int nib = 0;            // nib: two elements per byte (element 2k in the low half), stride 1
+	__device__ __forceinline__ int at(int i) const
+	{
+		const int k = i < rev_n ? rev_n - 1 - i : i;
+		if (nib) return p[k >> 1] >> ((k & 1) << 2) & 15;
+		return p[k * stride];
+	}
 };
 
 // ksw_qinit (ksw.c:60-110): shift / max of the matrix; profile in the striped order.  Group-collective.
@@ -292,11 +297,12 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 // SLEN > 0: cells in registers (pass_reg) when the query has at most SLEN segments, else the LDS version.
 template <int P, int SLEN = 0>
 __device__ __forceinline__ Res align2(const Work &w, int lane, int qlen, const uint8_t *q, int qstride, int tlen, const uint8_t *t, int tstride,
-                                      const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra)
+                                      const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra, bool t_nib = false)
 {
 	const int gl = gl_of<P>(lane);
 	int slen, shift, qmax;
 	SeqView qv = { q, qstride, 0 }, tv = { t, tstride, 0 };
+	tv.nib = t_nib ? 1 : 0;
 	qinit<P>(w, gl, qlen, qv, mat, slen, shift, qmax);
 	const int minsc = (xtra & XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & XSTOP) ? xtra & 0xffff : 0x10000;
 	const bool in_regs = SLEN > 0 && slen <= SLEN;
