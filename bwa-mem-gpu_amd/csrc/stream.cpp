@@ -77,25 +77,13 @@ struct Driver {
 	}
 };
 
-// Closing the reader (joining its threads, unmapping gigabytes of input: tens of milliseconds of page-table work under the address-space
-// lock) is nobody's critical path: it runs on a thread of its own -- and not at once: a run that follows immediately opens and first-touches
-// its own mappings under the same lock (measured: its open took 20-60 ms instead of 0.5), so the closer waits 200 ms, or until the next
-// hand-over or the unloading of the library asks for it.  Joined by the next run's hand-over.
+// Closing the reader (joining its threads, unmapping gigabytes of input: tens of milliseconds of page-table work) is nobody's critical path:
+// it runs on a thread of its own, joined by the next run or when the library is unloaded.  (Putting it off by 200 ms, so that a run that
+// follows at once does not open its files beside it -- 20-60 ms instead of 0.5 -- only moved the cost into that run: measured, no gain.)
 struct Reaper {
 	std::mutex mu; std::thread t;
-	std::mutex mw; std::condition_variable cv; bool hurry = false;
-	void finish() { { std::lock_guard<std::mutex> lk(mw); hurry = true; } cv.notify_all(); if (t.joinable()) t.join(); }
-	void close_later(bwahip_fastq *rd)
-	{
-		std::lock_guard<std::mutex> lk(mu);
-		finish();
-		hurry = false;
-		t = std::thread([this, rd] {
-			{ std::unique_lock<std::mutex> lw(mw); cv.wait_for(lw, std::chrono::milliseconds(200), [this] { return hurry; }); }
-			bwahip_fastq_close(rd);
-		});
-	}
-	~Reaper() { finish(); }
+	void close_later(bwahip_fastq *rd) { std::lock_guard<std::mutex> lk(mu); if (t.joinable()) t.join(); t = std::thread([rd] { bwahip_fastq_close(rd); }); }
+	~Reaper() { if (t.joinable()) t.join(); }
 };
 Reaper g_reaper;
 

@@ -56,6 +56,8 @@ def test_se_sam_identical_across_batches(ctx, small_index, tmp_path):
 @pytest.mark.parametrize("name,n,length,sub,indel,nn,seed", [
     ("pe150", 6000, 150, 10000, 1000, 300, 203),
     ("pe100_noisy", 6000, 100, 60000, 5000, 2000, 204),
+    ("pe200_noisy", 3000, 200, 40000, 4000, 1000, 205),       # mates of 161..249 bases: sixteen cells per lane in the byte kernel of the mate rescue
+    ("pe260_noisy", 3000, 260, 40000, 4000, 1000, 206),       # 250 bases and more: the word kernel (ksw_i16) does the rescue alignments
 ])
 def test_pe_sam_identical(ctx, small_index, tmp_path, name, n, length, sub, indel, nn, seed):
     fq1, fq2 = str(tmp_path / f"{name}_1.fq"), str(tmp_path / f"{name}_2.fq")
