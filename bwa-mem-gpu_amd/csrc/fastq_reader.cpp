@@ -540,7 +540,10 @@ int bwahip_fastq_open_mt(const char *path1, const char *path2, int n_threads, bw
 		r->fp[k].reset(new FileReader());
 		FileReader &p = *r->fp[k];
 		p.path = paths[k]; p.pool = r->pool.get(); p.blocks = r->blocks;
+		// how far the parser may run ahead of the consumer, per file: BWAHIP_READER_AHEAD_MB of raw text (default 72 MB with 8 threads: 2n + 2
+		// jobs of 4 MB; a driver with several contexts asks for batches in bursts and can set a whole batch's worth)
 		p.max_inflight = (size_t)(2 * n_threads + 2);
+		if (const char *e = getenv("BWAHIP_READER_AHEAD_MB")) { const long mb = atol(e); if (mb > 0) p.max_inflight = std::max<size_t>((size_t)mb * (1u << 20) / CHUNK, 2); }
 		if (strcmp(paths[k], "-") == 0) { p.gz = gzdopen(dup(0), "r"); if (!p.gz) return BWAHIP_EIO; gzbuffer(p.gz, 1 << 20); continue; }
 		p.fd = open(paths[k], O_RDONLY);
 		if (p.fd < 0) { fprintf(stderr, "[bwahip] cannot open %s\n", paths[k]); return BWAHIP_EIO; }
