@@ -226,8 +226,11 @@ public:
 
 // mem_sort_dedup_patch with bns == 0 (no patching), as mem_matesw calls it (bwamem_pair.c:203; bwamem.c:444-496).
 // L: the list (n entries), tmp: a spare list of the same capacity, keys / idx: sort scratch (n and 2n entries).
-__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, const ListRef L, const ListRef tmp, RegKey *keys, int *idx, int *stk, unsigned *lds256, int l, int *err)
+// re_ties: two entries of the list shared their `re` (the first sort's order between them, and with it the outcome of their redundancy
+// test, then depends on the arrangement the list came in: see incr_insert)
+__device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, const ListRef L, const ListRef tmp, RegKey *keys, int *idx, int *stk, unsigned *lds256, int l, int *err, bool &re_ties)
 {
+	re_ties = false;
 	if (n <= 1) return n;
 	for (int i = l; i < n; i += 64) { keys[i].k64 = L[i].re; keys[i].score = 0; keys[i].qb = 0; idx[i] = i; }
 	wsync();
@@ -242,6 +245,7 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, const 
 	wsync();
 	for (int i = l; i < n; i += 64) L[i] = tmp[i];
 	wsync();
+	for (int base = 0; base < n; base += 64) { const int i = base + l; if (__ballot(i >= 1 && i < n && L[i].re == L[i - 1].re)) re_ties = true; }
 	// redundancy (bwamem.c:451-480 without the patch branch).  The test that lets an entry take part (bwamem.c:453) reads rid, rb and re, which
 	// nothing here changes: it is evaluated 64 entries at a time, and lane 0 then visits the entries that passed
 	for (int cbase = 0; cbase < n; cbase += 64) {
@@ -297,12 +301,127 @@ __device__ __forceinline__ int sort_dedup_nopatch(const DevOpt &o, int n, const 
 	return m;
 }
 
+// One region into a list that the last mem_sort_dedup_patch left -- WITHOUT sorting it again (round 3).  mem_matesw re-runs
+// mem_sort_dedup_patch (bns == 0) on the whole list after every rescued hit (bwamem_pair.c:203); inside a repeat family that is a list of
+// thousands of regions, a hundred times per pair.  When no two entries share `re` and no two share (score, rb, qb), both sorts have exactly one
+// possible result whatever arrangement they start from, and the call is a function of the SET of regions; and a list that such a call returned
+// is a fixed point of it: every pair of survivors within max_chain_gap of each other went through the redundancy test (bwamem.c:459-470: the
+// later one's loop only ends early when that one is excluded) and passed.  So for L + {b} the only tests with a new outcome are b's:
+//   * b's own turn: the entries before it in `re` order and within reach (bwamem.c:454,456), nearest first; a redundant pair excludes the one
+//     of lower score -- b, which ends its turn, or the other (q on a tie), and b goes on;
+//   * then the turn of every entry after b in `re` order whose loop reaches back to b, in `re` order, while b is not excluded: the entries it
+//     passes on the way are old acquaintances (or excluded by b a moment ago, and skipped);
+// then the excluded ones go and b, if it stays, takes its place in the order of the second sort.  Conditions checked here, else the caller
+// takes the general path: b shares its `re` or its (score, rb, qb) with no entry; no entry of another contig lies near b in `re` order (the
+// reference's loops stop at one); at most 64 entries are within reach.  Returns false when a condition fails (nothing changed).
+__device__ __forceinline__ bool incr_insert(const DevOpt &o, int &n_io, const ListRef L, const ListRef tmp, DevReg b, int *idx, int l)
+{
+	const int n = n_io;
+	const int64_t gap = o.max_chain_gap;
+	bool fail = false;
+	int pos = 0, n_cand = 0;
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + l;
+		bool cand = false, before = false, bad = false;
+		if (i < n) {
+			const int64_t xrb = L[i].rb, xre = L[i].re;
+			const int xrid = L[i].rid, xsc = L[i].score, xqb = L[i].qb;
+			bad = xre == b.re || (xsc == b.score && xrb == b.rb && xqb == b.qb) || (xrid != b.rid && xre > b.rb - gap - 1 && xre < b.re + gap + 65536);
+			cand = xrid == b.rid && ((xre < b.re && b.rb < xre + gap) || (xre > b.re && xrb < b.re + gap));
+			before = xsc > b.score || (xsc == b.score && (xrb < b.rb || (xrb == b.rb && xqb < b.qb)));
+		}
+		if (__ballot(bad)) fail = true;
+		pos += __popcll(__ballot(before));
+		const unsigned long long cm = __ballot(cand);
+		if (cand) { const int slot = n_cand + __popcll(cm & ((1ull << l) - 1)); if (slot < 64) idx[slot] = i; }
+		n_cand += __popcll(cm);
+	}
+	if (fail || n_cand > 64) return false;
+	wsync();
+	// lane k holds candidate k
+	const bool have = l < n_cand;
+	const int ci = have ? idx[l] : 0;
+	int64_t xrb = 0, xre = 0; int xqb = 0, xqe = 0, xsc = 0;
+	if (have) { xrb = L[ci].rb; xre = L[ci].re; xqb = L[ci].qb; xqe = L[ci].qe; xsc = L[ci].score; }
+	const bool is_pred = have && xre < b.re;
+	// order: predecessors by descending re (rank 0 = nearest), then successors by ascending re
+	int rank = 0;
+	for (int s_ = 0; s_ < n_cand; ++s_) {
+		const int64_t ore = __shfl(xre, s_);
+		const bool opred = ore < b.re;
+		if (have && opred == is_pred && (is_pred ? ore > xre : ore < xre)) ++rank;
+	}
+	const int n_pred = __popcll(__ballot(is_pred));
+	bool exc = false, b_exc = false;
+	for (int r = 0; r < n_cand && !b_exc; ++r) {
+		const bool pred_turn = r < n_pred;
+		const unsigned long long who = __ballot(have && is_pred == pred_turn && rank == (pred_turn ? r : r - n_pred));
+		const int k = __ffsll((long long)who) - 1;               // exactly one lane (all re differ)
+		const int64_t krb = __shfl(xrb, k), kre = __shfl(xre, k);
+		const int kqb = __shfl(xqb, k), kqe = __shfl(xqe, k), ksc = __shfl(xsc, k);
+		// p = the later one in `re` order, q = the earlier one (bwamem.c:457-466)
+		const int64_t prb = pred_turn ? b.rb : krb, pre = pred_turn ? b.re : kre, qrb = pred_turn ? krb : b.rb, qre = pred_turn ? kre : b.re;
+		const int pqb = pred_turn ? b.qb : kqb, pqe = pred_turn ? b.qe : kqe, qqb = pred_turn ? kqb : b.qb, qqe = pred_turn ? kqe : b.qe;
+		const int psc = pred_turn ? b.score : ksc, qsc = pred_turn ? ksc : b.score;
+		const int64_t orr = qre - prb, oq = qqb < pqb ? qqe - pqb : pqe - qqb;
+		const int64_t mr = qre - qrb < pre - prb ? qre - qrb : pre - prb;
+		const int64_t mq = qqe - qqb < pqe - pqb ? qqe - qqb : pqe - pqb;
+		if ((float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq) {
+			const bool p_goes = psc < qsc;
+			if (pred_turn) { if (p_goes) b_exc = true; else if (l == k) exc = true; }
+			else           { if (p_goes) { if (l == k) exc = true; } else b_exc = true; }
+		}
+	}
+	const unsigned long long em = __ballot(exc);
+	int m = n;
+	if (em) {                                                     // drop the excluded entries, order kept
+		if (exc) L[ci].qe = L[ci].qb;
+		wsync();
+		m = 0;
+		for (int base = 0; base < n; base += 64) {
+			const int i = base + l;
+			const bool keep = i < n && L[i].qe > L[i].qb;
+			const unsigned long long km = __ballot(keep);
+			if (keep) tmp[m + __popcll(km & ((1ull << l) - 1))] = L[i];
+			m += __popcll(km);
+		}
+		wsync();
+		for (int i = l; i < m; i += 64) L[i] = tmp[i];
+		wsync();
+		pos = 0;
+		for (int base = 0; base < m; base += 64) {
+			const int i = base + l;
+			bool before = false;
+			if (i < m) { const int64_t yrb = L[i].rb; const int ysc = L[i].score, yqb = L[i].qb; before = ysc > b.score || (ysc == b.score && (yrb < b.rb || (yrb == b.rb && yqb < b.qb))); }
+			pos += __popcll(__ballot(before));
+		}
+	}
+	if (!b_exc) {
+		for (int hi = m; hi > pos; hi -= 64) {                    // shift [pos, m) up by one, from the top, 64 at a time
+			const int i = hi - 1 - l;
+			DevReg v;
+			const bool mv = i >= pos;
+			if (mv) v = L[i];
+			wsync();
+			if (mv) L[i + 1] = v;
+			wsync();
+		}
+		b.n_comp = 1;
+		if (l == 0) L[pos] = b;
+		++m;
+		wsync();
+	}
+	n_io = m;
+	return true;
+}
+
 // mem_matesw (bwamem_pair.c:137-206): anchor `an` (a region of one end), mate read r_m (length l_ms), mate list L (n_ma).
 // P = 16: byte kernel (l_ms * a < 250), P = 8: word kernel.  Returns the new length of the mate list.
 template <int P>
 __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int slot0, int r_m, int l_ms, const ListRef L, int n_ma, const ListRef tmp, RegKey *keys, int *idx,
-                      const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new, unsigned long long &n_inline)
+                      const MsLds &m, uint8_t *slab, int l, unsigned long long &n_sw, unsigned long long &n_new, unsigned long long &n_inline, bool &clean)
 {
+	// clean: the list is what a mem_sort_dedup_patch without ties returned (or that plus incr_insert steps): one more call is the identity
 	const DevOpt &opt = a.opt;
 	const DevIndex &ix = a.ix;
 	const int64_t l_pac = ix.l_pac;
@@ -323,6 +442,7 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 	int n = 0;
 	for (int r = 0; r < 4; ++r) {
 		if (skip >> r & 1) continue;
+		bool general = !clean;                                    // this orientation ends with the general mem_sort_dedup_patch
 		const int is_rev = (r >> 1) != (r & 1);
 		int64_t rb, re;
 		if (ms_window(a, an, r, l_ms, rb, re)) {
@@ -368,6 +488,11 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 				b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
 				b.score = aln.score; b.csub = aln.score2;
 				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+				const unsigned long long tki = wall_clock64();
+				const bool done = !general && incr_insert(opt, n_ma, L, tmp, b, idx, l);
+				if (done) { ++n_new; if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tki); }
+				else {
+				general = true;
 				// insert b keeping the list sorted by score (bwamem_pair.c:194-199)
 				int at = n_ma;
 				for (int base = 0; base < n_ma; base += 64) {
@@ -387,10 +512,11 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 				if (l == 0) L[at] = b;
 				++n_ma; ++n_new;
 				wsync();
+				}
 			}
 			++n;
 		}
-		if (n) { const unsigned long long tk3 = wall_clock64(); n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, reinterpret_cast<unsigned*>(m.h + 128), l, a.err); if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }   // (m.h + 128: 256 bytes into the array -- a base register of the sort's table accesses stays inside LDS whatever offset gets folded)
+		if (n && general) { const unsigned long long tk3 = wall_clock64(); bool ties; n_ma = sort_dedup_nopatch(opt, n_ma, L, tmp, keys, idx, m.stk, reinterpret_cast<unsigned*>(m.h + 128), l, a.err, ties); clean = !ties; if (l == 0) atomicAdd(&a.counters[6], wall_clock64() - tk3); }   // (m.h + 128: 256 bytes into the array -- a base register of the sort's table accesses stays inside LDS whatever offset gets folded)
 	}
 	return n_ma;
 }
@@ -493,15 +619,17 @@ __global__ __launch_bounds__(64, BIG ? 2 : 1) void k_matesw(PairLaunch a)
 				for (int k = l; k < n_list[i ^ 1]; k += 64) s_list[k] = G[k];
 				wsync();
 				const MsLds m = { s_q, s_mat, s_prof, s_h, s_keys, s_idx, s_stk, s_tw, 4096, s_cm };
+				bool clean = false;
 				for (int j = 0; j < a.nb[r]; ++j)
-					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, s_list, n_list[i ^ 1], s_tmp, s_keys, s_idx, m, slab, l, n_sw, n_new, n_inline);
+					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, s_list, n_list[i ^ 1], s_tmp, s_keys, s_idx, m, slab, l, n_sw, n_new, n_inline, clean);
 			} else {
 				DevReg *tmp = a.pe_tmp + a.pe_base[rm];
 				RegKey *keys = reinterpret_cast<RegKey*>(a.pe_keys) + a.pe_base[rm];
 				int *idx = a.pe_idx + 2 * a.pe_base[rm];
 				const MsLds m = { s_q, s_mat, s_prof, s_h, keys, idx, s_stk, s_tw, 4096, s_cm };
+				bool clean = false;
 				for (int j = 0; j < a.nb[r]; ++j)
-					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, ListRef::global(G), n_list[i ^ 1], ListRef::global(tmp), keys, idx, m, slab, l, n_sw, n_new, n_inline);
+					n_list[i ^ 1] = matesw<P>(a, snap[j], (int)a.sw_base[r] + 4 * j, rm, l_ms, ListRef::global(G), n_list[i ^ 1], ListRef::global(tmp), keys, idx, m, slab, l, n_sw, n_new, n_inline, clean);
 			}
 			if (in_lds) { wsync(); for (int k = l; k < n_list[i ^ 1]; k += 64) G[k] = s_list[k]; wsync(); }
 		}
