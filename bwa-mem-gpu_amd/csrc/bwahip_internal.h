@@ -162,7 +162,7 @@ struct ChainLaunch {
 	int *flt;                                    // 8 ints per seed slot: per-position data for k_chain_flt
 	int *heavy_list, *heavy_count;               // reads whose overlap filter is deferred to k_chain_flt
 	const int *seed_cnt; int *perm, *perm_counts;   // k_chain's launch order: reads with many seeds first, like sizes together (nullptr = identity)
-	int *big_list, *big_count; int big_min, big_max;   // reads with big_min < seeds <= big_max go to k_chain_big (nullptr: off)
+	int *big_list, *big_count; int big_min, big_max, mid_max, glb_grid;   // reads with big_min < seeds <= big_max go to k_chain_big (nullptr: off)
 };
 int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipStream_t st3, hipEvent_t fork, hipEvent_t join, hipEvent_t join3);
 int launch_chain_flt(const ChainLaunch &a, hipStream_t st);

@@ -47,6 +47,7 @@ struct Knobs {
 	int sa_intv = 1;            // BWAHIP_SA_INTV: interval of the SA table in HBM (1: every row, 8 bytes each; the index files' own interval or more: the files' table as it is); a table that would take over a quarter of the free HBM is built at the next interval that fits
 	int kmer_k = 14;            // BWAHIP_KMER_K: the interval table holds the bi-intervals of all strings of up to kmer_k bases (16 bytes each, 4^k of them per length: 14 -> 5.7 GB, 15 -> 23 GB, 16 -> 92 GB; 0 or 1: no table); never longer than log4 of the text, nor than a quarter of the free HBM
 	int heavy_mult = -1;        // BWAHIP_HEAVY_MULT: hand a read to k_smem_heavy after heavy_mult x len extends (0: never; -1: 10 for reads up to 200 bases, 30 above -- a 250 bp read at 5 % error needs 2 500 extends on average, and the hand-off is for the outliers)
+	int chain_mid_max = 1536, chain_big_max = 3200, chain_glb_grid = 2048;   // BWAHIP_CHAIN_MID_MAX / _BIG_MAX / _GLB_GRID: seeds up to which a read's B-tree lives in 77 KB / 150 KB of LDS (beyond: in global memory), and the workgroups of that last kernel
 	int chain_big_min = 512;    // BWAHIP_CHAIN_BIG_MIN: seeds above which a wavefront-per-read chaining kernel takes the read (< 0: off)
 	int rank_sort_min = 2;      // BWAHIP_RANK_SORT_MIN: dedup lists at least this long are sorted by the whole wavefront (shorter: the one-lane restatement of ks_introsort)
 	int spec_min_chains = 16;   // BWAHIP_SPEC_MIN_CHAINS: chains from which k_extend_spec extends ahead of time (0: off)
@@ -60,7 +61,7 @@ struct Knobs {
 	{
 		auto geti = [](const char *k, int &v) { if (const char *e = getenv(k)) v = atoi(e); };
 		geti("BWAHIP_INTV_CAP", intv_cap); geti("BWAHIP_SMEM_LANES", smem_lanes); geti("BWAHIP_HEAVY_MULT", heavy_mult); geti("BWAHIP_SA_INTV", sa_intv); geti("BWAHIP_KMER_K", kmer_k);
-		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final); geti("BWAHIP_GPU_PAIR", gpu_pair);
+		geti("BWAHIP_CHAIN_BIG_MIN", chain_big_min); geti("BWAHIP_CHAIN_MID_MAX", chain_mid_max); geti("BWAHIP_CHAIN_BIG_MAX", chain_big_max); geti("BWAHIP_CHAIN_GLB_GRID", chain_glb_grid); geti("BWAHIP_RANK_SORT_MIN", rank_sort_min); geti("BWAHIP_SPEC_MIN_CHAINS", spec_min_chains); geti("BWAHIP_EXT_LDS_WINDOW", ext_lds_window); geti("BWAHIP_GPU_FINAL", gpu_final); geti("BWAHIP_GPU_PAIR", gpu_pair);
 		verbose = getenv("BWAHIP_VERBOSE") != nullptr;
 		e2e_log = getenv("BWAHIP_E2E_LOG") != nullptr;
 		dump_ext = getenv("BWAHIP_DUMP_EXT");

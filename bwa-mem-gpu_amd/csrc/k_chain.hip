@@ -379,7 +379,7 @@ constexpr int MID_NODES = 400, MID_SEEDS = 1536;             // two workgroups p
 constexpr int SMALL_NODES = 72, SMALL_SEEDS = 256;           // eleven per CU for reads of a few dozen to 256 seeds (14 KB)
 constexpr int GLB_LDS = 2048 + 512;                          // reads beyond big_max seeds: nodes in their global slots, this much LDS for the sort's small tables (+ the unused ends)
 // classes of the wavefront-per-read kernels: 0 = up to SMALL_SEEDS, 1 = up to MID_SEEDS, 2 = up to big_max, 3 = beyond (global nodes)
-__device__ __forceinline__ int coop_class(int S, int big_max) { return S <= SMALL_SEEDS ? 0 : S <= MID_SEEDS ? 1 : S <= big_max ? 2 : 3; }
+__device__ __forceinline__ int coop_class(int S, int mid_max, int big_max) { return S <= SMALL_SEEDS ? 0 : S <= mid_max ? 1 : S <= big_max ? 2 : 3; }
 
 template <bool BIG>
 __device__ __forceinline__ void chain_read(const ChainLaunch &a, int r, BtNode *lds_nodes, int lds_node_cap = BIG_NODES, uint8_t *lds_area = nullptr, int lds_bytes = 0)
@@ -579,7 +579,7 @@ __global__ void k_chain_classify(ChainLaunch a)
 	if (r >= a.n_reads) return;
 	const int S = (int)(a.seed_base[r + 1] - a.seed_base[r]);
 	if (S > a.big_min) {
-		const int cls = coop_class(S, a.big_max);
+		const int cls = coop_class(S, a.mid_max, a.big_max);
 		a.big_list[(size_t)cls * a.n_reads + atomicAdd(&a.big_count[cls], 1)] = r;
 	}
 }
@@ -598,6 +598,24 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainLaunch a)
 		if (h >= n_mine) break;
 		chain_read<true>(a, a.big_list[(size_t)CLS * a.n_reads + h], nodes, NODES, s_area, LDS_BYTES);
 		__threadfence_block(); __syncthreads();
+	}
+	// The kernel with the nodes in global memory is slower per read but is not held to one or two workgroups per CU by 77 / 150 KB of LDS.
+	// When a batch has thousands of reads for the LDS kernels (a human-like repeat load: they alone took 0.25 s per million reads), its
+	// workgroups help out: a queue that began with more reads than the LDS kernel's workgroups take in two rounds is emptied together with
+	// that kernel (with a few reads in the queue -- the ordinary batch -- the faster kernels keep them all).
+	if (CLS == 3) {
+		for (int cls = 2; cls >= 1; --cls) {
+			const int n_cls = a.big_count[cls];
+			if (n_cls <= (cls == 2 ? 2 * 256 : 2 * 1024)) continue;
+			for (;;) {
+				int h = n_cls;
+				if ((threadIdx.x & 63) == 0) h = atomicAdd(&a.big_count[4 + cls], 1);
+				h = __shfl(h, 0);
+				if (h >= n_cls) break;
+				chain_read<true>(a, a.big_list[(size_t)cls * a.n_reads + h], nullptr, 0, s_area, LDS_BYTES);
+				__threadfence_block(); __syncthreads();
+			}
+		}
 	}
 }
 
@@ -718,7 +736,7 @@ int launch_chain(const ChainLaunch &a, hipStream_t st, hipStream_t st2, hipStrea
 	if (a.big_list) {                                        // reads with more than big_min seeds: a wavefront each, in kernels that run beside k_chain
 		hipLaunchKernelGGL(k_chain_classify, dim3((a.n_reads + 255) / 256), dim3(256), 0, st, a);
 		if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(st2, fork, 0) != hipSuccess || hipStreamWaitEvent(st3, fork, 0) != hipSuccess) return BWAHIP_ENODEV;
-		hipLaunchKernelGGL((k_chain_big<0, 3>), dim3(256), dim3(64), 0, st2, a);              // the longest first
+		hipLaunchKernelGGL((k_chain_big<0, 3>), dim3(a.glb_grid), dim3(64), 0, st2, a);       // the longest first
 		hipLaunchKernelGGL((k_chain_big<BIG_NODES, 2>), dim3(256), dim3(64), 0, st2, a);
 		hipLaunchKernelGGL((k_chain_big<MID_NODES, 1>), dim3(1024), dim3(64), 0, st3, a);
 		hipLaunchKernelGGL((k_chain_big<SMALL_NODES, 0>), dim3(256 * 11), dim3(64), 0, st3, a);

@@ -676,7 +676,7 @@ int run_pipeline(bwahip_ctx *c, const bwahip_opt_t *opt, bool timed, bool dump)
 		if (big_min >= 0) {
 			if ((rc = c->d_chain_big.ensure(((size_t)4 * n + 8) * 4))) return rc;
 			HIP_TRY(hipMemsetAsync(c->d_chain_big.p, 0, 32, c->stream));
-			cl.big_list = c->d_chain_big.as<int>() + 8; cl.big_count = c->d_chain_big.as<int>(); cl.big_min = big_min; cl.big_max = 3200;   // 800 LDS nodes >= 0.24 x seeds (every node but the root holds >= 5 keys)
+			cl.big_list = c->d_chain_big.as<int>() + 8; cl.big_count = c->d_chain_big.as<int>(); cl.big_min = big_min; cl.big_max = std::min(c->knobs.chain_big_max, 3200); cl.mid_max = std::min(c->knobs.chain_mid_max, 1536); cl.glb_grid = std::max(c->knobs.chain_glb_grid, 64);   // 800 LDS nodes >= 0.24 x seeds (every node but the root holds >= 5 keys)
 		}
 		HIP_TRY(hipMemsetAsync(c->d_heavy.p, 0, 16, c->stream));
 		if (dump) { cl.dbg_chains = c->d_dbg_chains.as<DevChain>(); cl.dbg_seeds = c->d_dbg_seeds.as<DevSeed>(); cl.dbg_chain_n = c->d_dbg_chain_n.as<int>(); }
