@@ -507,15 +507,25 @@ __device__ __forceinline__ int heavy_smem1(const SmemLaunch &a, HeavyRead &r, in
 
 __global__ __launch_bounds__(256) void k_smem_heavy(SmemLaunch a)
 {
-	__shared__ uint4 lists[4][BWAHIP_MAX_READ_LEN + 8];
+	// a list per wavefront, sized for the longest read of the batch (dynamic LDS: 4 x (len + 8) x 16 bytes -- 10 KB at 150 bases, so that
+	// registers, not 45 KB of LDS for the longest read the library takes, decide how many reads a CU works on)
+	extern __shared__ uint4 lists_dyn[];
+	const int list_cap = (a.seq4_stride - 1) * 16 + 8;
 	const int lane = lane_id();
 	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
 	HeavyRead r;
-	r.L = lists[threadIdx.x >> 6];
+	r.L = lists_dyn + (size_t)(threadIdx.x >> 6) * list_cap;
 	r.n_ext = r.n_blk = 0;
 	const unsigned n_heavy = *a.heavy_n;
 	unsigned n_out = 0;
-	for (unsigned h = (unsigned)wave; h < n_heavy; h += (unsigned)n_waves) {
+	// the reads come from a queue (a.queue[3]): they differ by a factor of ten in their number of extensions, and with a fixed share per
+	// wavefront the kernel lasted as long as the unluckiest share
+	(void)wave; (void)n_waves;
+	for (;;) {
+		unsigned h = 0;
+		if (lane == 0) h = atomicAdd(a.queue + 3, 1u);
+		h = (unsigned)__shfl((int)h, 0);
+		if (h >= n_heavy) break;
 		const int rd = a.heavy_list[h];
 		r.qrow = a.seq4 + (size_t)rd * a.seq4_stride; r.qwi = -1; r.qw = 0;
 		r.U = a.raw + (size_t)rd * a.cap;
@@ -687,9 +697,10 @@ int launch_intv_sort(const SmemLaunch &a, hipStream_t st)
 
 int launch_smem_heavy(const SmemLaunch &a, hipStream_t st)
 {
-	int waves = a.groups_total < 4096 ? a.groups_total : 4096;   // one scratch region per wavefront
+	int waves = a.groups_total < 5120 ? a.groups_total : 5120;   // one scratch region per wavefront; 5 wavefronts per SIMD fit (99 VGPRs)
 	if (waves < 4) return BWAHIP_EINVAL;
-	hipLaunchKernelGGL(k_smem_heavy, dim3(waves / 4), dim3(256), 0, st, a);
+	const size_t lds = (size_t)4 * ((a.seq4_stride - 1) * 16 + 8) * 16;
+	hipLaunchKernelGGL(k_smem_heavy, dim3(waves / 4), dim3(256), lds, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
 
