@@ -49,7 +49,9 @@ template <int P> __device__ __forceinline__ bool group_any(bool p, int lane)
 	return ((m >> (lane & ~(P - 1))) & ((1ull << P) - 1)) != 0;
 }
 
-__device__ __forceinline__ int sat_sub_u(int a, int b) { const int s = a - b; return s < 0 ? 0 : s; }
+// _mm_subs_epu8 / _mm_subs_epu16 on values held in 32-bit registers: both operands are non-negative wherever this is called (cell values after
+// the maxima with E / F, gap penalties), so the unsigned saturating subtraction -- one v_sub_u32 with the clamp bit -- is max(a - b, 0)
+__device__ __forceinline__ int sat_sub_u(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
 
 // Sequence access: element i of a byte string read with a stride, optionally with its first `rev_n` elements reversed
 // (revseq of ksw.c:358 on a prefix, the rest untouched).
