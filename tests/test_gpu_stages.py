@@ -300,6 +300,8 @@ def test_sa_table_densities_agree(small_index, tmp_path, monkeypatch):
     for intv in (32, 4, 1):
         monkeypatch.setenv("BWAHIP_SA_INTV", str(intv))
         with bw.Context(small_index["prefix"], 0) as c:
+            fp = c.index_footprint()
+            assert fp["sa_intv"] == intv and fp["sa_gb"] == round((seq_len // intv + 1) * 8 / 1e9, 2)
             got[intv] = c.kat_sa(rows)
             sams[intv] = c.process_seqs(names, seqs, quals)
             if intv == 1:
