@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Manual (not collected by pytest) large parity run on the GPU box: reads WITH indels, N's and chimeras (tools/simgen) against a repeat-rich genome,
 single-end and paired-end, several read lengths / error rates; bwahip_process_seqs vs the CPU path (oracle/_ref/bwaref if present,
-else the C restatement), byte for byte.   python tests/manual_big_parity.py [genome_mbp] [reads]"""
+else the C restatement), byte for byte.   python tests/manual_big_parity.py [genome_mbp] [reads] [default|human-like]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,11 +12,12 @@ import tools_py as tp
 
 mbp = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+profile = sys.argv[3] if len(sys.argv) > 3 else "default"
 d = "/dev/shm/big_parity"; os.makedirs(d, exist_ok=True)
-prefix = f"{d}/g{mbp}"
+prefix = f"{d}/g{mbp}" + ("h" if profile != "default" else "")
 lens = tp.contig_lengths(mbp * 1000000)
 if not os.path.exists(prefix + ".sa"):
-    tp.write_fasta(prefix + ".fa", tp.make_genome(38, lens, repeats=True), lens)
+    tp.write_fasta(prefix + ".fa", tp.make_genome(38, lens, repeats=True, profile=profile), lens)
     bw.make_index(prefix + ".fa", prefix)
 exe = common.BWAREF if common.have_ref() else common.ORACLE
 body = lambda s: b"\n".join(l for l in s.split(b"\n") if not l.startswith(b"@"))
