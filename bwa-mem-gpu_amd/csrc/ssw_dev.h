@@ -183,7 +183,9 @@ __device__ __forceinline__ Res pass(const Work &w, int lane, int slen, int shift
 // measured with 10 segments); in registers only the profile row comes from LDS, and its loads do not depend on the chain.
 // Exactly the arithmetic of pass<>; w.H0/H1/E are not touched, w.Hmax receives the best column at the end (for callers
 // that want it; qe is computed here).
-template <int P, int SLEN>
+// FULL: every lane's query has exactly SLEN segments (slen == SLEN in the whole wavefront -- reads of one length): the per-segment tests
+// `j < slen` are compile-time true and the unrolled loops have no branches around their bodies
+template <int P, int SLEN, bool FULL = false>
 __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int shift, int qmax, int tlen, const SeqView &t,
                                         int o_del, int e_del, int o_ins, int e_ins, int minsc, int endsc)
 {
@@ -202,22 +204,22 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 	{
 		const int8_t *S = w.prof + (size_t)(tlen > 0 ? t.at(0) : 0) * slen * P;
 #pragma unroll
-		for (int j = 0; j < SLEN; ++j) sv[j] = j < slen ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
+		for (int j = 0; j < SLEN; ++j) sv[j] = (FULL || j < slen) ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
 	}
 	for (int i = 0; i < tlen; ++i) {
 		int svn[SLEN];
 		{
 			const int8_t *S = w.prof + (size_t)t.at(i + 1 < tlen ? i + 1 : i) * slen * P;
 #pragma unroll
-			for (int j = 0; j < SLEN; ++j) svn[j] = j < slen ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
+			for (int j = 0; j < SLEN; ++j) svn[j] = (FULL || j < slen) ? (is8 ? (int)(uint8_t)S[j * P + gl] : (int)S[j * P + gl]) : 0;
 		}
 		int f = 0, mxv = 0, last = 0;
 #pragma unroll
-		for (int j = 0; j < SLEN; ++j) if (j == slen - 1) last = H[j];
+		for (int j = 0; j < SLEN; ++j) if (FULL ? j == SLEN - 1 : j == slen - 1) last = H[j];
 		int h = shift_up<P>(last, gl);
 #pragma unroll
 		for (int j = 0; j < SLEN; ++j) {
-			if (j < slen) {
+			if ((FULL || j < slen)) {
 				int e = E[j];
 				if (is8) { h += sv[j]; h = h > 255 ? 255 : h; h = sat_sub_u(h, shift); }
 				else { h += sv[j]; h = h > 32767 ? 32767 : h < -32768 ? -32768 : h; }
@@ -240,7 +242,7 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 			f = shift_up<P>(f, gl);
 #pragma unroll
 			for (int j = 0; j < SLEN; ++j) {
-				if (j < slen && !stop) {
+				if ((FULL || j < slen) && !stop) {
 					int hh = H[j];
 					hh = hh > f ? hh : f;
 					H[j] = hh;
@@ -268,11 +270,11 @@ __device__ __forceinline__ Res pass_reg(const Work &w, int lane, int slen, int s
 	if (!is8 || r.score != 255) {
 		int best = -1;
 #pragma unroll
-		for (int j = 0; j < SLEN; ++j) if (j < slen) { const int v = Hm[j] & 0xffff; best = best > v ? best : v; }
+		for (int j = 0; j < SLEN; ++j) if ((FULL || j < slen)) { const int v = Hm[j] & 0xffff; best = best > v ? best : v; }
 		best = group_max<P>(best);
 		int qe = 1 << 30;
 #pragma unroll
-		for (int j = 0; j < SLEN; ++j) if (j < slen && (Hm[j] & 0xffff) == best) { const int k = j + gl * slen; qe = qe < k ? qe : k; }
+		for (int j = 0; j < SLEN; ++j) if ((FULL || j < slen) && (Hm[j] & 0xffff) == best) { const int k = j + gl * slen; qe = qe < k ? qe : k; }
 		qe = group_min<P>(qe);
 		r.qe = slen > 0 ? qe : -1;
 		if (minsc < 0x10000 && (w.colmax || w.colmax8)) {
@@ -308,7 +310,9 @@ __device__ __forceinline__ Res align2(const Work &w, int lane, int qlen, const u
 	qinit<P>(w, gl, qlen, qv, mat, slen, shift, qmax);
 	const int minsc = (xtra & XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & XSTOP) ? xtra & 0xffff : 0x10000;
 	const bool in_regs = SLEN > 0 && slen <= SLEN;
-	Res r = in_regs ? pass_reg<P, SLEN ? SLEN : 1>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc)
+	const bool full = SLEN > 0 && __ballot(slen != SLEN) == 0;      // (wave-uniform; all lanes of the wavefront are here)
+	Res r = full ? pass_reg<P, SLEN ? SLEN : 1, true>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc)
+	      : in_regs ? pass_reg<P, SLEN ? SLEN : 1>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc)
 	                : pass<P, true>(w, lane, slen, shift, qmax, tlen, tv, o_del, e_del, o_ins, e_ins, minsc, endsc);
 	if ((xtra & XSTART) == 0 || ((xtra & XSUBO) && r.score < (xtra & 0xffff))) return r;
 	if (P == 16 && r.score == 255) return r;                      // qe unknown: the reference reads out of bounds here; unreachable (score <= qlen*a < 250)
