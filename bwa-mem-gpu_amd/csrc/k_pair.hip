@@ -91,19 +91,6 @@ __global__ void k_pe_prepare(PairLaunch a)
 	a.pe_cap[p << 1 | 1] = a.reg_n[p << 1 | 1] + nb[0] * n_live;
 }
 
-// skip mask of mem_matesw (bwamem_pair.c:143-150) for anchor `arb` against list ma[0..n): bit r set = orientation r needs no rescue
-__device__ __forceinline__ int skip_mask_seq(const PairLaunch &a, int64_t arb, const DevReg *ma, int n)
-{
-	int m = 0;
-	for (int d = 0; d < 4; ++d) m |= a.pes[d].failed ? 1 << d : 0;
-	for (int k = 0; k < n; ++k) {
-		int64_t dist;
-		const int d = infer_dir(a.ix.l_pac, arb, ma[k].rb, &dist);
-		if (dist >= a.pes[d].low && dist <= a.pes[d].high) m |= 1 << d;
-	}
-	return m;
-}
-
 // the reference window of mem_matesw for anchor `an`, orientation r and a mate of l_ms bases (bwamem_pair.c:153-166);
 // true when the alignment is attempted (same contig as the anchor, window at least one seed long)
 __device__ __forceinline__ bool ms_window(const PairLaunch &a, const DevReg &an, int r, int l_ms, int64_t &rb, int64_t &re)
