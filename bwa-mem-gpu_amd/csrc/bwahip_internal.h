@@ -285,6 +285,7 @@ struct PairLaunch {
 	// the alignments of the anchors that need one on the lists as mem_align1_core left them, done ahead of the sequential pass,
 	// four per wavefront (k_matesw_sw): slot = sw_base[anchor's read] + 4 * anchor + orientation
 	const int64_t *sw_base; int *sw_cnt; SwRes *sw_res; int *sw_tasks; int2 *sw_info; int *sw_n;
+	int *sw_n8; int sw_cap;                      // the word kernel's tasks (mates of 250..256 bases x a): taken from the END of sw_tasks (sw_cap entries)
 	uint8_t *slab; size_t slab_stride;           // k_matesw: per-workgroup global scratch (reference window, column maxima, long-query working set)
 	unsigned int *queue;                         // k_matesw's work-queue heads (one per instantiation)
 	unsigned long long *counters;                // [0] SW calls, [1] rescued regions
@@ -302,7 +303,7 @@ int launch_pe_prepare(const PairLaunch &a, hipStream_t st);      // nb, pe_cap
 int launch_pe_copy(const PairLaunch &a, hipStream_t st);         // copy lists into pe_regs, list the pairs that need rescue
 int launch_matesw(const PairLaunch &a, int grid, hipStream_t st);
 int launch_resc_order(const PairLaunch &a, int n_resc, int *scratch, hipStream_t st);   // rescue list by list length, longest first (scratch: 3 n_resc + 8 ints)
-int launch_matesw_sw(const PairLaunch &a, int n_tasks, int max_len, hipStream_t st);   // max_len: longest read of the batch
+int launch_matesw_sw(const PairLaunch &a, int n_tasks, int n_tasks8, int max_len, hipStream_t st);   // max_len: longest read of the batch
 int launch_pair(const PairLaunch &a, int n_listed, hipStream_t st);   // subset 2: n_listed pairs of resc_list
 size_t matesw_slab_bytes(int64_t window);
 int launch_sam_pe(const FinLaunch &a, bool write, hipStream_t st, int read_lo = 0, int read_hi = -1);

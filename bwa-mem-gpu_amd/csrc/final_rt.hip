@@ -99,7 +99,7 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 	pl.logtab = c->d_logtab.as<double>();
 	pl.regs = c->d_regs.as<DevReg>(); pl.reg_base = c->d_reg_base.as<int64_t>(); pl.reg_n = c->d_reg_n.as<int>();
 	unsigned long long *fm = c->d_fmisc.as<unsigned long long>();
-	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5; pl.sw_n = (int*)(fm + 14); pl.queue = (unsigned int*)(fm + 16);
+	pl.err = (int*)(fm + 2); pl.resc_n = (int*)(fm + 4); pl.counters = fm + 5; pl.sw_n = (int*)(fm + 14); pl.queue = (unsigned int*)(fm + 16); pl.sw_n8 = (int*)(fm + 18);
 	bwahip_pestat_t pes[4];
 	if (pes0) memcpy(pes, pes0, sizeof pes);
 	else {
@@ -149,24 +149,25 @@ static int run_pe_rescue(bwahip_ctx *c, const bwahip_opt_t *opt, const DevOpt &d
 		const size_t S = (size_t)(n_slots ? n_slots : 1);
 		if ((rc = c->d_sw_res.ensure(S * sizeof(SwRes))) || (rc = c->d_sw_tasks.ensure(S * 4)) || (rc = c->d_sw_info.ensure(S * 8))) return rc;
 		HIP_TRY(hipMemsetAsync(c->d_sw_res.p, 0, S * sizeof(SwRes), c->stream));
-		pl.sw_res = c->d_sw_res.as<SwRes>(); pl.sw_tasks = c->d_sw_tasks.as<int>(); pl.sw_info = c->d_sw_info.as<int2>();
+		pl.sw_res = c->d_sw_res.as<SwRes>(); pl.sw_tasks = c->d_sw_tasks.as<int>(); pl.sw_info = c->d_sw_info.as<int2>(); pl.sw_cap = (int)S;
 	}
 	const size_t R = (size_t)(cap ? cap : 1);
 	c->total_regs = cap;                                          // from here on the region slots are the paired-end ones
 	if ((rc = c->d_pe_regs.ensure(R * sizeof(DevReg))) || (rc = c->d_pe_tmp.ensure(R * sizeof(DevReg))) || (rc = c->d_pe_keys.ensure(R * 16)) || (rc = c->d_pe_idx.ensure(R * 8))) return rc;
 	pl.pe_regs = c->d_pe_regs.as<DevReg>(); pl.pe_tmp = c->d_pe_tmp.as<DevReg>(); pl.pe_keys = c->d_pe_keys.p; pl.pe_idx = c->d_pe_idx.as<int>();
 	if ((rc = launch_pe_copy(pl, c->stream))) return rc;
-	int n_resc = 0, n_sw_tasks = 0;
+	int n_resc = 0, n_sw_tasks = 0, n_sw_tasks8 = 0;
+	HIP_TRY(hipMemcpyAsync(&n_sw_tasks8, pl.sw_n8, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&n_resc, pl.resc_n, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&n_sw_tasks, pl.sw_n, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	n_resc_out = n_resc;
 	c->last_pe_counters[3] = (unsigned long long)n_resc;
-	c->last_sw_tasks = (unsigned long long)n_sw_tasks;
-	if (n_resc > 0 || n_sw_tasks > 0) {
+	c->last_sw_tasks = (unsigned long long)n_sw_tasks + (unsigned long long)n_sw_tasks8;
+	if (n_resc > 0 || n_sw_tasks > 0 || n_sw_tasks8 > 0) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
 		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-		if ((rc = launch_matesw_sw(pl, n_sw_tasks, c->max_len, c->stream2))) return rc;   // the alignments against the unrescued lists, all at once
+		if ((rc = launch_matesw_sw(pl, n_sw_tasks, n_sw_tasks8, c->max_len, c->stream2))) return rc;   // the alignments against the unrescued lists, all at once
 		if (n_resc > 0) {
 			if ((rc = c->d_resc_ord.ensure(((size_t)3 * n_resc + 8) * 4)) || (rc = launch_resc_order(pl, n_resc, c->d_resc_ord.as<int>(), c->stream2))) return rc;
 			const int grid = std::min(n_resc, 2048);

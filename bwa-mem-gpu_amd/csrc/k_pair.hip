@@ -121,6 +121,7 @@ __device__ __forceinline__ bool ms_window(const PairLaunch &a, const DevReg &an,
 }
 
 constexpr int SW_TW = 1024;                                  // widest window k_matesw_sw takes (wider ones are aligned inside k_matesw)
+constexpr int SW8_QMAX = 256;                                // longest mate the word kernel's alignments are run ahead for (32 cells per lane in registers)
 
 // per pair: copy both lists into their (larger) slots; list the pair for k_matesw if any anchor has an orientation left.
 // W lanes work on the pair (1: a thread of k_pe_copy; 64: a wavefront of k_pe_copy_big, for the pairs with more than PE_COPY_SMALL regions --
@@ -155,13 +156,17 @@ __device__ __forceinline__ void pe_copy_pair(const PairLaunch &a, int p, int l)
 			if (sk == 15) continue;
 			need = true;
 			// the alignments this anchor asks for against the unrescued list can be done ahead, in parallel (k_matesw_sw)
-			if (l_ms * a.opt.a < 250)
+			// (mates of l_ms * a < 250: the byte kernel, k_matesw_sw; up to 256 bases beyond that: the word kernel, k_matesw_sw8, its tasks from the
+			// end of the same array; longer mates are aligned inside k_matesw)
+			const bool byte_k = l_ms * a.opt.a < 250;
+			if (byte_k || l_ms <= SW8_QMAX)
 				for (int o = W > 1 ? l : 0; o < 4; o += W > 1 ? 64 : 1) {
 					int64_t rb, re;
 					if ((sk >> o & 1) || !ms_window(a, src[j], o, l_ms, rb, re) || re - rb > SW_TW) continue;
 					const int slot = (int)a.sw_base[r] + 4 * j + o;
 					a.sw_res[slot].state = 1;
-					a.sw_tasks[atomicAdd(a.sw_n, 1)] = slot;
+					if (byte_k) a.sw_tasks[atomicAdd(a.sw_n, 1)] = slot;
+					else a.sw_tasks[a.sw_cap - 1 - atomicAdd(a.sw_n8, 1)] = slot;
 					a.sw_info[slot] = make_int2(r, j << 2 | o);
 				}
 		}
@@ -436,7 +441,7 @@ __device__ __forceinline__ int matesw(const PairLaunch &a, const DevReg an, int 
 			const unsigned long long tk0 = wall_clock64();
 			const int tlen = (int)(re - rb);
 			ssw::Res aln = { 0, -1, -1, -1, -1, -1, -1 };
-			const SwRes pre = P == 16 ? a.sw_res[slot0 + r] : SwRes{ 0, 0, 0, 0, 0, 0, 0, 0 };
+			const SwRes pre = a.sw_res[slot0 + r];
 			const unsigned long long tk1 = wall_clock64();
 			if (pre.state == 2) {                                     // done ahead by k_matesw_sw (same anchor, orientation, window)
 				aln.score = pre.score; aln.te = pre.te; aln.qe = pre.qe; aln.score2 = pre.score2; aln.te2 = pre.te2; aln.tb = pre.tb; aln.qb = pre.qb;
@@ -548,6 +553,43 @@ __global__ __launch_bounds__(64) void k_matesw_sw(PairLaunch a)
 	ssw::Res aln;
 	if (QMAX <= 160 || l_ms <= 160) aln = ssw::align2<16, 10>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra, true);
 	else aln = ssw::align2<16, 16>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra, true);
+	if (gl == 0) { SwRes o_ = { 2, aln.score, aln.te, aln.qe, aln.score2, aln.te2, aln.tb, aln.qb }; a.sw_res[slot] = o_; }
+}
+
+// The same for mates of 250 bases x a and more (up to SW8_QMAX bases): the word kernel (ksw_i16: ksw_align2 takes it when KSW_XBYTE is not set,
+// bwamem_pair.c:171), eight lanes per alignment, eight alignments per wavefront, 32 cells per lane in registers.
+__global__ __launch_bounds__(64) void k_matesw_sw8(PairLaunch a)
+{
+	__shared__ int8_t s_mat[32];
+	__shared__ uint8_t s_tw[8][SW_TW / 2];
+	__shared__ uint16_t s_cm[8][SW_TW];
+	__shared__ uint8_t s_q[8][SW8_QMAX];
+	__shared__ int8_t s_prof[8][5 * SW8_QMAX];
+	const int lane_ = lane(), g = lane_ >> 3, gl = lane_ & 7;
+	if (lane_ < 25) s_mat[lane_] = a.opt.mat[lane_];
+	__syncthreads();
+	const int n_tasks = *a.sw_n8;
+	const int t = (int)blockIdx.x * 8 + g;
+	if (t >= n_tasks) return;
+	const int slot = a.sw_tasks[a.sw_cap - 1 - t];
+	const int2 info = a.sw_info[slot];
+	const int r = info.x, j = info.y >> 2, o = info.y & 3, rm = r ^ 1;
+	const DevReg an = a.regs[a.reg_base[r] + j];
+	const int l_ms = (int)(a.off[rm + 1] - a.off[rm]);
+	const uint8_t *ms = a.seq + a.off[rm];
+	int64_t rb, re;
+	ms_window(a, an, o, l_ms, rb, re);                            // eligibility was established by k_pe_copy
+	const int tlen = (int)(re - rb);
+	const int is_rev = (o >> 1) != (o & 1);
+	for (int i = gl; 2 * i < tlen; i += 8)
+		s_tw[g][i] = (uint8_t)(ref_base(a.ix, rb + 2 * i) | (2 * i + 1 < tlen ? ref_base(a.ix, rb + 2 * i + 1) : 0) << 4);
+	if (is_rev) for (int i = gl; i < l_ms; i += 8) { const uint8_t c = ms[i]; s_q[g][l_ms - 1 - i] = c < 4 ? 3 - c : 4; }
+	else for (int i = gl; i < l_ms; i += 8) s_q[g][i] = ms[i];
+	__threadfence_block();
+	ssw::Work w;
+	w.prof = s_prof[g]; w.H0 = w.H1 = w.E = w.Hmax = nullptr; w.colmax = s_cm[g]; w.colmax8 = nullptr;
+	const int xtra = ssw::XSUBO | ssw::XSTART | (a.opt.min_seed_len * a.opt.a);
+	const ssw::Res aln = ssw::align2<8, SW8_QMAX / 8>(w, lane_, l_ms, s_q[g], 1, tlen, s_tw[g], 1, s_mat, a.opt.o_del, a.opt.e_del, a.opt.o_ins, a.opt.e_ins, xtra, true);
 	if (gl == 0) { SwRes o_ = { 2, aln.score, aln.te, aln.qe, aln.score2, aln.te2, aln.tb, aln.qb }; a.sw_res[slot] = o_; }
 }
 
@@ -949,9 +991,10 @@ int launch_matesw(const PairLaunch &a, int grid, hipStream_t st)
 	hipLaunchKernelGGL((k_matesw<8, false>), dim3(grid), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 }
-int launch_matesw_sw(const PairLaunch &a, int n_tasks, int max_len, hipStream_t st)
+int launch_matesw_sw(const PairLaunch &a, int n_tasks, int n_tasks8, int max_len, hipStream_t st)
 {
-	if (n_tasks <= 0) return 0;
+	if (n_tasks8 > 0) hipLaunchKernelGGL(k_matesw_sw8, dim3((n_tasks8 + 7) / 8), dim3(64), 0, st, a);
+	if (n_tasks <= 0) return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
 	if (max_len <= 160) hipLaunchKernelGGL(k_matesw_sw<160>, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
 	else hipLaunchKernelGGL(k_matesw_sw<256>, dim3((n_tasks + 3) / 4), dim3(64), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : BWAHIP_ENODEV;
